@@ -1,0 +1,181 @@
+/*
+ * pnpi.h -- C ABI of libpnpi.so: the MI355X (gfx950) implementation of PnPInversion's direct-inversion +
+ * Prompt-to-Prompt hot path.  Plain pointers and sizes only; no C++ / torch types cross this boundary.
+ *
+ * The reference (cure-lab/PnPInversion) is pure Python and has no FFI of its own; its "operator API" for this path is the
+ * duck-typed pipeline object used by the modules under models/p2p/.  Each entry point below names the reference interface it
+ * replaces (file:line in /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pnpi_status otherwise; pnpi_last_error() gives the message.
+ *   - all tensor arguments are DEVICE pointers to contiguous memory unless the name ends in _host.
+ *   - public layouts are the reference's: latents / eps fp32 NCHW, context fp32 [rows,77,768], images uint8 HWC.
+ *   - all work is enqueued on the HIP stream given to pnpi_create(); nothing synchronises the device.
+ *   - one pnpi_ctx per (process, GPU); a ctx is not thread-safe.
+ *   - UNet batch-row convention (models/p2p/p2p_guidance_forward.py:108,170; inversion.py:305,382), per image:
+ *       rows_per_image = 4 : [uncond_src, uncond_tgt, cond_src, cond_tgt]   (controllers act on rows 2,3 only)
+ *       rows_per_image = 1 : DDIM inversion (cond_src only)
+ */
+#ifndef PNPI_H
+#define PNPI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pnpi_ctx pnpi_ctx;
+
+typedef enum {
+  PNPI_OK = 0,
+  PNPI_EINVAL = -1,  /* bad argument */
+  PNPI_ESHAPE = -2,  /* unsupported shape / configuration */
+  PNPI_EHIP = -3,    /* HIP runtime error */
+  PNPI_ESTATE = -4,  /* call sequence error (e.g. weights not loaded) */
+  PNPI_ENOMEM = -5
+} pnpi_status;
+
+/* Architecture of the Stable-Diffusion-1.x UNet / VAE (diffusers UNet2DConditionModel / AutoencoderKL constructor args,
+ * models/edict/my_diffusers/models/unet_2d_condition.py:57-82, vae.py:508-519).  SD-1.x: see pnpi_config_sd1(). */
+typedef struct {
+  int in_channels, out_channels;   /* 4, 4 */
+  int n_blocks;                    /* 4 */
+  int block_out_channels[4];       /* 320, 640, 1280, 1280 */
+  int block_has_attn[4];           /* 1, 1, 1, 0  (CrossAttnDownBlock2D x3, DownBlock2D) */
+  int layers_per_block;            /* 2 */
+  int heads;                       /* 8  (diffusers' "attention_head_dim") */
+  int cross_dim;                   /* 768 */
+  int ctx_len;                     /* 77 */
+  int sample_size;                 /* 64 (latent H = W) */
+  int norm_groups;                 /* 32 */
+  int n_train_timesteps;           /* 1000 */
+  int vae_in_channels;             /* 3 */
+  int vae_latent_channels;         /* 4 */
+  int vae_n_blocks;                /* 4 */
+  int vae_block_out_channels[4];   /* 128, 256, 512, 512 */
+  int vae_layers_per_block;        /* 2 */
+  int vae_norm_groups;             /* 32 */
+} pnpi_model_config;
+
+void pnpi_config_sd1(pnpi_model_config* cfg);
+
+typedef struct {
+  const char* name;   /* diffusers state-dict key prefixed with "unet." or "vae." */
+  const void* data;   /* device pointer, contiguous, PyTorch layout ([out,in,kh,kw] / [out,in] / [n]) */
+  int dtype;          /* 0 = fp32, 1 = fp16 */
+  int ndim;
+  int64_t shape[4];
+} pnpi_named_tensor;
+
+/* Declarative Prompt-to-Prompt controller (one per image).  Replaces the per-layer Python callback
+ * controller(attn, is_cross, place_in_unet) of models/p2p/attention_control.py:44,178-190 for the controller classes
+ * AttentionStore (:214), AttentionReplace (:301), AttentionRefine (:317), AttentionReweight (:338) and LocalBlend (:95).
+ * All pointers are HOST pointers; tables are copied at the call. */
+typedef struct {
+  int kind;                        /* 0 = none / AttentionStore (no effect on the output), 1 = edit */
+  int n_alpha_rows;                /* rows of cross_alpha (num_steps + 1 = 51) */
+  const float* cross_alpha_host;   /* [n_alpha_rows][77]  get_time_words_attention_alpha, utils/utils.py:117-135 */
+  const float* mapper_host;        /* [77][77] source-token w -> target-token j weights (Replace: seq_aligner.py:152-185;
+                                      Refine: one-hot of mapper[j]==w, seq_aligner.py:107-118; Reweight alone: identity) */
+  const float* alphas_host;        /* [77] Refine blend weights (1 for Replace)            attention_control.py:319-321 */
+  const float* equalizer_host;     /* [77] Reweight scales (1 if none)                     attention_control.py:84-92,343 */
+  int self_replace_lo, self_replace_hi;  /* num_self_replace = (0, 30)                     attention_control.py:295-297 */
+  int self_replace_max_tokens;     /* 1024 (32**2)                                          attention_control.py:259 */
+  int lb_enabled;                  /* LocalBlend                                            attention_control.py:95-147 */
+  int lb_start;                    /* start_blend = int(0.2 * steps) = 10 */
+  float lb_threshold;              /* 0.3 */
+  const float* lb_alpha_host;      /* [2][77] alpha_layers one-hot rows (src prompt, tgt prompt) */
+} pnpi_ctrl_desc;
+
+typedef struct {
+  uint64_t unet_sample_forwards;   /* number of UNet batch rows evaluated (x 803.27 GFLOP each for SD-1.x) */
+  uint64_t unet_calls;
+  uint64_t vae_encodes, vae_decodes;
+  double executed_gemm_flops;      /* 2*M*N*K over every MFMA GEMM/conv launch, padding included */
+  double executed_attn_flops;
+} pnpi_counters;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+/* replaces StableDiffusionPipeline.from_pretrained(...).to(device)             models/p2p_editor.py:23-25 */
+int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images);
+void pnpi_destroy(pnpi_ctx* ctx);
+const char* pnpi_last_error(const pnpi_ctx* ctx);
+int pnpi_load_weights(pnpi_ctx* ctx, const pnpi_named_tensor* tensors, int n);
+int pnpi_missing_weights(const pnpi_ctx* ctx, char* names_out, size_t cap);   /* returns count of unloaded slots */
+/* packed fp16/fp32 weight arena, for the one start-up RCCL broadcast */
+int pnpi_weight_arena(pnpi_ctx* ctx, void** ptr, size_t* bytes);
+/* receiving ranks of that broadcast call this instead of pnpi_load_weights */
+int pnpi_mark_all_loaded(pnpi_ctx* ctx);
+/* DDIMScheduler tables: alphas_cumprod[n_train] (fp32) and final_alpha_cumprod    models/p2p_editor.py:18-22 */
+int pnpi_set_scheduler(pnpi_ctx* ctx, const float* alphas_cumprod_host, int n_train, float final_alpha_cumprod);
+int pnpi_get_counters(const pnpi_ctx* ctx, pnpi_counters* out);
+int pnpi_reset_counters(pnpi_ctx* ctx);
+
+/* ---- level 1: operator boundary (keeps the loops under models/p2p/ usable unmodified) ---------------------------- */
+/* model.unet(latents, t, encoder_hidden_states=context)["sample"]    inversion.py:273, p2p_guidance_forward.py:109 */
+int pnpi_unet_forward(pnpi_ctx* ctx, const float* latents, int rows, int rows_per_image, int t, const float* context,
+                      const pnpi_ctrl_desc* ctrl_host /* nullable, [rows/4] */, int cur_step, float* eps_out);
+/* controller.step_callback -> LocalBlend.__call__ (attention_control.py:108-121,253-256) for level-1 drivers:
+ * latents [nimg][2][4][h][w] updated in place, using the maps accumulated by the preceding pnpi_unet_forward calls */
+int pnpi_local_blend(pnpi_ctx* ctx, float* latents, int nimg, int step_index);
+/* model.vae.encode(x)['latent_dist'].mean  (x fp32 NCHW in [-1,1])                     utils/utils.py:78 */
+int pnpi_vae_encode(pnpi_ctx* ctx, const float* x_nchw, int n, int height, int width, float* mean_out);
+/* model.vae.decode(z)['sample']                                                        utils/utils.py:61 */
+int pnpi_vae_decode(pnpi_ctx* ctx, const float* z_nchw, int n, int lat_h, int lat_w, float* sample_out);
+/* image2latent: uint8 HWC -> 0.18215 * mean                                             utils/utils.py:68-80 */
+int pnpi_image2latent(pnpi_ctx* ctx, const uint8_t* img_hwc, int n, int height, int width, float* z_out);
+/* latent2image: decode(z / 0.18215) -> (x/2+.5).clamp(0,1)*255 -> uint8 HWC              utils/utils.py:58-66 */
+int pnpi_latent2image(pnpi_ctx* ctx, const float* z_nchw, int n, int lat_h, int lat_w, uint8_t* img_hwc_out);
+/* DirectInversion.next_step (inversion.py:262-270): alpha values are taken from the scheduler table */
+int pnpi_ddim_next_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, const float* sample, size_t n, float* out);
+/* DirectInversion.prev_step (inversion.py:247-260) == DDIMSchedulerDev.step (scheduler_dev.py:38-95), eta = 0 */
+int pnpi_ddim_prev_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, const float* sample, size_t n, float* out);
+/* fused CFG + prev_step + direct-inversion offset (inversion.py:383-389; p2p_guidance_forward.py:110-114).
+ *   eps [nimg][2R][E]; x [nimg][R][E]; target (nullable) [nimg][E] -> offset_out = target - prev, x_out = prev + offset;
+ *   else noise_loss (nullable) [nimg][R][E] added to the first offset_rows rows. */
+int pnpi_cfg_ddim_prev(pnpi_ctx* ctx, const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems,
+                       float guidance_scale, int t, int step_ratio, const float* noise_loss, int offset_rows,
+                       const float* target, float* offset_out, float* x_out);
+
+/* ---- level 2: loop boundary (whole phases device-resident, no host round trip per step) ------------------------- */
+/* DirectInversion.ddim_loop (inversion.py:308-319): latents_out [nsteps+1][nimg][4][h][w]; timesteps_host = scheduler.timesteps */
+int pnpi_ddim_invert(pnpi_ctx* ctx, const float* z0, int nimg, const float* ctx_cond /*[nimg][77][768]*/, int nsteps,
+                     const int* timesteps_host, float* latents_out);
+/* DirectInversion.offset_calculate (inversion.py:375-391): noise_loss_out [nsteps][nimg][2][4][h][w] */
+int pnpi_offset_calculate(pnpi_ctx* ctx, const float* ddim_latents /*[nsteps+1][nimg][...]*/, int nimg,
+                          const float* context4 /*[nimg][4][77][768]*/, int nsteps, const int* timesteps_host,
+                          float guidance_scale, float* noise_loss_out);
+/* direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) incl. controller + LocalBlend:
+ * latents_out [nimg][2][4][h][w].  ctrl_host: nullable or [nimg]. */
+int pnpi_edit_loop(pnpi_ctx* ctx, const float* x_T /*[nimg][4][h][w]*/, int nimg, const float* context4,
+                   const float* noise_loss /*[nsteps][nimg][2][...], nullable*/, int offset_rows,
+                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* timesteps_host, float guidance_scale,
+                   float* latents_out);
+
+/* ---- kernel-level entry points (used by tests/ and bench.py to exercise single kernels) ------------------------- */
+int pnpi_op_conv(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16, int C1, int C2, int B, int H, int W,
+                 int ksize, int stride, int pad, int upsample, int Ho, int Wo, const void* w_f16 /*[N][k*k*(C1+C2)]*/,
+                 const float* bias, const void* residual_f16, int N, void* out_nhwc_f16, int force_cfg, int force_split);
+int pnpi_op_gemm(pnpi_ctx* ctx, const void* a_f16, int lda, const void* w_f16, int ldw, int M, int N, int K, float alpha,
+                 const float* bias, const void* residual_f16, void* out_f16, int ldo, int vt_col0, void* outT,
+                 int vt_ld, int vt_f32, int rows_per_batch, int force_cfg, int force_split);
+int pnpi_op_groupnorm(pnpi_ctx* ctx, const void* x1, const void* x2, int C1, int C2, int B, int HW, int groups, float eps,
+                      const float* gamma, const float* beta, int silu, void* out);
+int pnpi_op_layernorm(pnpi_ctx* ctx, const void* x, int M, int C, float eps, const float* gamma, const float* beta, void* out);
+int pnpi_op_geglu(pnpi_ctx* ctx, const void* x, int M, int inner, void* out);
+int pnpi_op_softmax_rows(pnpi_ctx* ctx, void* x, int M, int N, int ld);
+int pnpi_op_attention(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
+                      int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
+                      const int* rows_dev /*[nrows][4]*/, int nrows);
+int pnpi_op_cross_edit(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
+                       int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
+                       const int* pairs_dev, int npairs, const void* mmatT_f16, const float* c1, const float* c2,
+                       const float* lb_alpha, float* lb_acc, int lb_slot0, int lb_nslots);
+int pnpi_op_local_blend(pnpi_ctx* ctx, const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th,
+                        float* latents, int nimg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNPI_H */

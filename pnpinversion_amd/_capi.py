@@ -1,0 +1,114 @@
+"""ctypes binding of libpnpi.so (include/pnpi.h).  There is no CPU fallback: if the HIP library is missing or a call
+fails, this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpnpi.so")
+
+PNPI_OK, PNPI_EINVAL, PNPI_ESHAPE, PNPI_EHIP, PNPI_ESTATE, PNPI_ENOMEM = 0, -1, -2, -3, -4, -5
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
+        ("block_out_channels", C.c_int * 4), ("block_has_attn", C.c_int * 4),
+        ("layers_per_block", C.c_int), ("heads", C.c_int), ("cross_dim", C.c_int), ("ctx_len", C.c_int),
+        ("sample_size", C.c_int), ("norm_groups", C.c_int), ("n_train_timesteps", C.c_int),
+        ("vae_in_channels", C.c_int), ("vae_latent_channels", C.c_int), ("vae_n_blocks", C.c_int),
+        ("vae_block_out_channels", C.c_int * 4), ("vae_layers_per_block", C.c_int), ("vae_norm_groups", C.c_int),
+    ]
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
+
+
+class CtrlDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("n_alpha_rows", C.c_int),
+        ("cross_alpha_host", C.POINTER(C.c_float)), ("mapper_host", C.POINTER(C.c_float)),
+        ("alphas_host", C.POINTER(C.c_float)), ("equalizer_host", C.POINTER(C.c_float)),
+        ("self_replace_lo", C.c_int), ("self_replace_hi", C.c_int), ("self_replace_max_tokens", C.c_int),
+        ("lb_enabled", C.c_int), ("lb_start", C.c_int), ("lb_threshold", C.c_float),
+        ("lb_alpha_host", C.POINTER(C.c_float)),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [("unet_sample_forwards", C.c_uint64), ("unet_calls", C.c_uint64), ("vae_encodes", C.c_uint64),
+                ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double)]
+
+
+# every symbol include/pnpi.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+SYMBOLS = {
+    "pnpi_config_sd1": (None, [C.POINTER(ModelConfig)]),
+    "pnpi_create": (_i, [C.POINTER(_vp), C.POINTER(ModelConfig), _i, _vp, _i, _i]),
+    "pnpi_destroy": (None, [_vp]),
+    "pnpi_last_error": (C.c_char_p, [_vp]),
+    "pnpi_load_weights": (_i, [_vp, C.POINTER(NamedTensor), _i]),
+    "pnpi_missing_weights": (_i, [_vp, C.c_char_p, _sz]),
+    "pnpi_weight_arena": (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "pnpi_mark_all_loaded": (_i, [_vp]),
+    "pnpi_set_scheduler": (_i, [_vp, C.POINTER(C.c_float), _i, _f]),
+    "pnpi_get_counters": (_i, [_vp, C.POINTER(Counters)]),
+    "pnpi_reset_counters": (_i, [_vp]),
+    "pnpi_unet_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(CtrlDesc), _i, _vp]),
+    "pnpi_local_blend": (_i, [_vp, _vp, _i, _i]),
+    "pnpi_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pnpi_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pnpi_image2latent": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pnpi_latent2image": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pnpi_ddim_next_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "pnpi_ddim_prev_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "pnpi_ddim_invert": (_i, [_vp, _vp, _i, _vp, _i, _ip, _vp]),
+    "pnpi_offset_calculate": (_i, [_vp, _vp, _i, _vp, _i, _ip, _f, _vp]),
+    "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _vp]),
+    "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
+    "pnpi_op_gemm": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
+    "pnpi_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
+    "pnpi_op_layernorm": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "pnpi_op_geglu": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pnpi_op_softmax_rows": (_i, [_vp, _vp, _i, _i, _i]),
+    "pnpi_op_attention": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i]),
+    "pnpi_op_cross_edit": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp,
+                                _vp, _vp, _vp, _i, _i]),
+    "pnpi_op_local_blend": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i]),
+}
+
+_lib = None
+
+
+class PnpiError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("libpnpi status %d: %s" % (status, message))
+        self.status = status
+
+
+def load_library(path=None):
+    """dlopen libpnpi.so and bind every symbol of include/pnpi.h.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            "libpnpi.so not found at %s -- build it with `python -m pnpinversion_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the native path." % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, ctx, status):
+    if status != 0:
+        msg = lib.pnpi_last_error(ctx)
+        raise PnpiError(status, msg.decode() if msg else "?")

@@ -1,0 +1,1187 @@
+// libpnpi: C-ABI entry points + the static SD-1.x UNet / VAE graph executor and the device-resident DI / P2P loops.
+// See include/pnpi.h for the reference interface each entry point replaces.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "model.h"
+
+// ---------------------------------------------------------------------------------------------------- error helpers
+// explicit status + message
+static int fail(pnpi_ctx* c, int status, const char* what) {
+  c->err = what;
+  return status;
+}
+// raw launch result: > 0 is a hipError_t, < 0 an argument/shape rejection by a launch wrapper
+static int fail_launch(pnpi_ctx* c, int code, const char* what) {
+  char buf[640];
+  if (code > 0) {
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s", code, hipGetErrorString((hipError_t)code), what);
+    c->err = buf;
+    return PNPI_EHIP;
+  }
+  snprintf(buf, sizeof(buf), "launch wrapper rejected arguments (code %d) in %s", code, what);
+  c->err = buf;
+  return PNPI_ESHAPE;
+}
+// CK: raw launch codes.  CKP: propagate an already-mapped pnpi_status (message already set).
+#define CK(x)                                 \
+  do {                                        \
+    int _r = (x);                             \
+    if (_r) return fail_launch(c, _r, #x);    \
+  } while (0)
+#define CKP(x)                \
+  do {                        \
+    int _r = (x);             \
+    if (_r) return _r;        \
+  } while (0)
+#define CKH(x)                                     \
+  do {                                             \
+    hipError_t _e = (x);                           \
+    if (_e != hipSuccess) return fail_launch(c, (int)_e, #x); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------- weight slots
+static void reg_mat(pnpi_ctx* c, const std::string& name, half_t* dst, int rows, int cols, int taps, int dst_ld, int cin_pad,
+                    int row0 = 0, int dh = 0, int Dp = 0) {
+  Slot s; s.kind = 0; s.dst = dst; s.rows = rows; s.cols = cols; s.taps = taps; s.dst_ld = dst_ld; s.cin_pad = cin_pad;
+  s.row0 = row0; s.dh = dh; s.Dp = Dp; s.n = 0; s.loaded = false;
+  c->slots[name] = s;
+}
+static void reg_vec(pnpi_ctx* c, const std::string& name, float* dst, int n) {
+  Slot s; s.kind = 1; s.dst = dst; s.rows = 0; s.cols = 0; s.taps = 0; s.dst_ld = 0; s.cin_pad = 0; s.row0 = 0; s.dh = 0; s.Dp = 0;
+  s.n = n; s.loaded = false;
+  c->slots[name] = s;
+}
+static half_t* walloc_h(pnpi_ctx* c, size_t n) { return (half_t*)c->warena.alloc(n * sizeof(half_t)); }
+static float* walloc_f(pnpi_ctx* c, size_t n) { return (float*)c->warena.alloc(n * sizeof(float)); }
+
+static ConvW make_conv(pnpi_ctx* c, const std::string& pre, int cin, int cout, int k, int cout_alloc = 0, float* bias_dst = nullptr) {
+  ConvW w; w.cin = cin; w.cin_pad = round_up_i(cin, 8); w.cout = cout; w.k = k;
+  int ra = cout_alloc > cout ? cout_alloc : cout;
+  w.w = walloc_h(c, (size_t)ra * k * k * w.cin_pad);
+  w.b = bias_dst ? bias_dst : walloc_f(c, ra);
+  reg_mat(c, pre + ".weight", w.w, cout, cin, k * k, k * k * w.cin_pad, w.cin_pad);
+  reg_vec(c, pre + ".bias", w.b, cout);
+  return w;
+}
+static LinW make_lin(pnpi_ctx* c, const std::string& pre, int in, int out) {
+  LinW l; l.in = in; l.out = out;
+  l.w = walloc_h(c, (size_t)out * in);
+  l.b = walloc_f(c, out);
+  reg_mat(c, pre + ".weight", l.w, out, in, 1, in, in);
+  reg_vec(c, pre + ".bias", l.b, out);
+  return l;
+}
+static NormW make_norm(pnpi_ctx* c, const std::string& pre, int ch) {
+  NormW n; n.c = ch; n.g = walloc_f(c, ch); n.b = walloc_f(c, ch);
+  reg_vec(c, pre + ".weight", n.g, ch);
+  reg_vec(c, pre + ".bias", n.b, ch);
+  return n;
+}
+static ResnetW make_resnet(pnpi_ctx* c, const std::string& pre, int cin, int cout, bool temb) {
+  ResnetW r; r.cin = cin; r.cout = cout;
+  r.n1 = make_norm(c, pre + ".norm1", cin);
+  if (temb) {
+    UNetW& u = c->unet;
+    r.temb_off = u.temb_total;
+    r.c1 = make_conv(c, pre + ".conv1", cin, cout, 3, 0, u.conv1_b + r.temb_off);
+    int te = 4 * c->cfg.block_out_channels[0];
+    reg_mat(c, pre + ".time_emb_proj.weight", u.temb_w, cout, te, 1, te, te, r.temb_off);
+    reg_vec(c, pre + ".time_emb_proj.bias", u.temb_b + r.temb_off, cout);
+    u.temb_total += cout;
+  } else {
+    r.temb_off = -1;
+    r.c1 = make_conv(c, pre + ".conv1", cin, cout, 3);
+  }
+  r.n2 = make_norm(c, pre + ".norm2", cout);
+  r.c2 = make_conv(c, pre + ".conv2", cout, cout, 3);
+  r.has_sc = cin != cout;
+  if (r.has_sc) r.sc = make_conv(c, pre + ".conv_shortcut", cin, cout, 1);
+  return r;
+}
+static TransformerW make_transformer(pnpi_ctx* c, const std::string& pre, int C, int place) {
+  TransformerW t; t.C = C; t.heads = c->cfg.heads; t.dh = C / t.heads; t.Dp = round_up_i(t.dh, 32); t.place = place; t.lb_slot0 = -1;
+  const int hd = t.heads * t.Dp, X = c->cfg.cross_dim;
+  t.gn = make_norm(c, pre + ".norm", C);
+  t.proj_in = make_conv(c, pre + ".proj_in", C, C, 1);
+  const std::string tb = pre + ".transformer_blocks.0";
+  t.ln1 = make_norm(c, tb + ".norm1", C);
+  t.ln2 = make_norm(c, tb + ".norm2", C);
+  t.ln3 = make_norm(c, tb + ".norm3", C);
+  t.w_qkv = walloc_h(c, (size_t)3 * hd * C);
+  reg_mat(c, tb + ".attn1.to_q.weight", t.w_qkv, C, C, 1, C, C, 0, t.dh, t.Dp);
+  reg_mat(c, tb + ".attn1.to_k.weight", t.w_qkv, C, C, 1, C, C, hd, t.dh, t.Dp);
+  reg_mat(c, tb + ".attn1.to_v.weight", t.w_qkv, C, C, 1, C, C, 2 * hd, t.dh, t.Dp);
+  t.o1 = make_lin(c, tb + ".attn1.to_out.0", C, C);
+  t.w_q2 = walloc_h(c, (size_t)hd * C);
+  reg_mat(c, tb + ".attn2.to_q.weight", t.w_q2, C, C, 1, C, C, 0, t.dh, t.Dp);
+  t.w_kv2 = walloc_h(c, (size_t)2 * hd * X);
+  reg_mat(c, tb + ".attn2.to_k.weight", t.w_kv2, C, X, 1, X, X, 0, t.dh, t.Dp);
+  reg_mat(c, tb + ".attn2.to_v.weight", t.w_kv2, C, X, 1, X, X, hd, t.dh, t.Dp);
+  t.o2 = make_lin(c, tb + ".attn2.to_out.0", C, C);
+  t.ff1 = make_lin(c, tb + ".ff.net.0.proj", C, 8 * C);
+  t.ff2 = make_lin(c, tb + ".ff.net.2", 4 * C, C);
+  t.proj_out = make_conv(c, pre + ".proj_out", C, C, 1);
+  return t;
+}
+static VaeAttnW make_vae_attn(pnpi_ctx* c, const std::string& pre, int C) {
+  VaeAttnW a; a.C = C;
+  a.gn = make_norm(c, pre + ".group_norm", C);
+  a.w_qkv = walloc_h(c, (size_t)3 * C * C);
+  a.b_qkv = walloc_f(c, 3 * C);
+  reg_mat(c, pre + ".query.weight", a.w_qkv, C, C, 1, C, C, 0);
+  reg_mat(c, pre + ".key.weight", a.w_qkv, C, C, 1, C, C, C);
+  reg_mat(c, pre + ".value.weight", a.w_qkv, C, C, 1, C, C, 2 * C);
+  reg_vec(c, pre + ".query.bias", a.b_qkv, C);
+  reg_vec(c, pre + ".key.bias", a.b_qkv + C, C);
+  reg_vec(c, pre + ".value.bias", a.b_qkv + 2 * C, C);
+  a.proj = make_lin(c, pre + ".proj_attn", C, C);
+  return a;
+}
+
+static int temb_total_channels(const pnpi_model_config& g) {
+  int n = g.n_blocks, total = 0;
+  for (int i = 0; i < n; ++i) total += g.layers_per_block * g.block_out_channels[i];
+  total += 2 * g.block_out_channels[n - 1];
+  for (int i = 0; i < n; ++i) total += (g.layers_per_block + 1) * g.block_out_channels[n - 1 - i];
+  return total;
+}
+
+static void build_model(pnpi_ctx* c) {
+  const pnpi_model_config& g = c->cfg;
+  c->slots.clear();
+  UNetW& u = c->unet;
+  u = UNetW();
+  const int n = g.n_blocks, C0 = g.block_out_channels[0], TE = 4 * C0;
+  const int sumC = temb_total_channels(g);
+  u.temb_w = walloc_h(c, (size_t)sumC * TE);
+  u.temb_b = walloc_f(c, sumC);
+  u.conv1_b = walloc_f(c, sumC);
+  u.temb_total = 0;
+  u.conv_in = make_conv(c, "unet.conv_in", g.in_channels, C0, 3);
+  u.t1 = make_lin(c, "unet.time_embedding.linear_1", C0, TE);
+  u.t2 = make_lin(c, "unet.time_embedding.linear_2", TE, TE);
+  std::vector<TransformerW*> down_stored, up_stored;
+  int out_ch = C0;
+  u.down_res.resize(n); u.down_attn.resize(n);
+  for (int i = 0; i < n; ++i) {
+    int in_ch = out_ch; out_ch = g.block_out_channels[i];
+    for (int j = 0; j < g.layers_per_block; ++j) {
+      std::string pre = "unet.down_blocks." + std::to_string(i);
+      u.down_res[i].push_back(make_resnet(c, pre + ".resnets." + std::to_string(j), j == 0 ? in_ch : out_ch, out_ch, true));
+      if (g.block_has_attn[i]) u.down_attn[i].push_back(make_transformer(c, pre + ".attentions." + std::to_string(j), out_ch, 0));
+    }
+    if (i != n - 1) u.down_samp.push_back(make_conv(c, "unet.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", out_ch, out_ch, 3));
+  }
+  const int Cl = g.block_out_channels[n - 1];
+  u.mid_res[0] = make_resnet(c, "unet.mid_block.resnets.0", Cl, Cl, true);
+  u.mid_attn = make_transformer(c, "unet.mid_block.attentions.0", Cl, 1);
+  u.mid_res[1] = make_resnet(c, "unet.mid_block.resnets.1", Cl, Cl, true);
+  u.up_res.resize(n); u.up_attn.resize(n);
+  out_ch = Cl;
+  for (int i = 0; i < n; ++i) {
+    int prev_out = out_ch; out_ch = g.block_out_channels[n - 1 - i];
+    int in_ch = g.block_out_channels[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+    for (int j = 0; j <= g.layers_per_block; ++j) {
+      int skip_ch = (j == g.layers_per_block) ? in_ch : out_ch;
+      int res_in = (j == 0) ? prev_out : out_ch;
+      std::string pre = "unet.up_blocks." + std::to_string(i);
+      u.up_res[i].push_back(make_resnet(c, pre + ".resnets." + std::to_string(j), res_in + skip_ch, out_ch, true));
+      if (g.block_has_attn[n - 1 - i]) u.up_attn[i].push_back(make_transformer(c, pre + ".attentions." + std::to_string(j), out_ch, 2));
+    }
+    if (i != n - 1) u.up_samp.push_back(make_conv(c, "unet.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_ch, out_ch, 3));
+  }
+  u.norm_out = make_norm(c, "unet.conv_norm_out", C0);
+  u.conv_out = make_conv(c, "unet.conv_out", C0, g.out_channels, 3);
+
+  // LocalBlend layers: attention_store["down_cross"][2:4] + ["up_cross"][:3] over the stored (<= 32^2 token) cross maps
+  // (models/p2p/attention_control.py:112,223)
+  std::vector<std::pair<TransformerW*, int>> dstored, ustored;
+  for (int i = 0; i < n; ++i) {
+    int tok = (g.sample_size >> i) * (g.sample_size >> i);
+    for (auto& t : u.down_attn[i]) if (tok <= 1024) dstored.push_back({&t, tok});
+  }
+  for (int i = 0; i < n; ++i) {
+    int s = g.sample_size >> (n - 1 - i);
+    for (auto& t : u.up_attn[i]) if (s * s <= 1024) ustored.push_back({&t, s * s});
+  }
+  u.lb_nslots = 0; u.lb_tokens = 0;
+  if (dstored.size() >= 4 && ustored.size() >= 3) {
+    std::vector<std::pair<TransformerW*, int>> lb = {dstored[2], dstored[3], ustored[0], ustored[1], ustored[2]};
+    bool same = true;
+    for (auto& e : lb) same = same && e.second == lb[0].second;
+    int side = (int)lroundf(sqrtf((float)lb[0].second));
+    if (same && side * side == lb[0].second) {
+      for (size_t k = 0; k < lb.size(); ++k) lb[k].first->lb_slot0 = (int)k * g.heads;
+      u.lb_nslots = 5 * g.heads;
+      u.lb_tokens = lb[0].second;
+    }
+  }
+
+  // ---- VAE
+  VaeW& v = c->vae;
+  v = VaeW();
+  const int vn = g.vae_n_blocks, L = g.vae_latent_channels;
+  const int* vb = g.vae_block_out_channels;
+  v.e_conv_in = make_conv(c, "vae.encoder.conv_in", g.vae_in_channels, vb[0], 3);
+  v.e_res.resize(vn);
+  int o = vb[0];
+  for (int i = 0; i < vn; ++i) {
+    int in_ch = o; o = vb[i];
+    for (int j = 0; j < g.vae_layers_per_block; ++j)
+      v.e_res[i].push_back(make_resnet(c, "vae.encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? in_ch : o, o, false));
+    if (i != vn - 1) v.e_down.push_back(make_conv(c, "vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", o, o, 3));
+  }
+  const int Vl = vb[vn - 1];
+  v.e_mid[0] = make_resnet(c, "vae.encoder.mid_block.resnets.0", Vl, Vl, false);
+  v.e_attn = make_vae_attn(c, "vae.encoder.mid_block.attentions.0", Vl);
+  v.e_mid[1] = make_resnet(c, "vae.encoder.mid_block.resnets.1", Vl, Vl, false);
+  v.e_norm_out = make_norm(c, "vae.encoder.conv_norm_out", Vl);
+  v.e_conv_out = make_conv(c, "vae.encoder.conv_out", Vl, 2 * L, 3, 8);
+  v.quant = make_conv(c, "vae.quant_conv", 2 * L, 2 * L, 1, 8);
+  v.post_quant = make_conv(c, "vae.post_quant_conv", L, L, 1, 8);
+  v.d_conv_in = make_conv(c, "vae.decoder.conv_in", L, Vl, 3);
+  v.d_mid[0] = make_resnet(c, "vae.decoder.mid_block.resnets.0", Vl, Vl, false);
+  v.d_attn = make_vae_attn(c, "vae.decoder.mid_block.attentions.0", Vl);
+  v.d_mid[1] = make_resnet(c, "vae.decoder.mid_block.resnets.1", Vl, Vl, false);
+  v.d_res.resize(vn);
+  o = Vl;
+  for (int i = 0; i < vn; ++i) {
+    int prev = o; o = vb[vn - 1 - i];
+    for (int j = 0; j <= g.vae_layers_per_block; ++j)
+      v.d_res[i].push_back(make_resnet(c, "vae.decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? prev : o, o, false));
+    if (i != vn - 1) v.d_up.push_back(make_conv(c, "vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", o, o, 3));
+  }
+  v.d_norm_out = make_norm(c, "vae.decoder.conv_norm_out", vb[0]);
+  v.d_conv_out = make_conv(c, "vae.decoder.conv_out", vb[0], g.vae_in_channels, 3);
+}
+
+// ---------------------------------------------------------------------------------------------------- op wrappers
+static half_t* talloc(pnpi_ctx* c, size_t n) { return (half_t*)c->temp.alloc(n * sizeof(half_t)); }
+static half_t* palloc(pnpi_ctx* c, size_t n) { return (half_t*)c->persist.alloc(n * sizeof(half_t)); }
+
+static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, const NormW& nw, int G, float eps,
+                 int silu, half_t* out) {
+  if (c->dry) return 0;
+  return launch_groupnorm(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, c->gn_partial, c->st);
+}
+
+struct VtOut { void* outT = nullptr; int col0 = 1 << 30; int ld = 0; int f32 = 0; int rpb = 1; };
+
+static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int C2, int B, int H, int W, const ConvW& w, int stride,
+                   int pad, int ups, const float* bias, const half_t* res, half_t* out, int Ho, int Wo, int N = -1,
+                   const VtOut* vt = nullptr) {
+  GemmP p; gemm_defaults(p);
+  int C1p = C2 ? C1 : w.cin_pad;  // single-source inputs are stored with the padded channel count
+  p.x1 = x1; p.x2 = x2; p.C1 = C1p; p.C2 = C2; p.ldx1 = C1p; p.ldx2 = C2;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.ksize = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
+  p.K = w.k * w.k * (C1p + C2); p.w = w.w; p.ldw = p.K;
+  p.M = B * Ho * Wo; p.N = N > 0 ? N : w.cout;
+  p.bias = bias; p.res = res; p.ldres = p.N; p.out = out; p.ldo = p.N;
+  if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
+  c->ctr.executed_gemm_flops += 2.0 * p.M * p.N * p.K;
+  if (c->dry) return 0;
+  return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
+}
+
+static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const half_t* w, int ldw, int N, const float* bias,
+                   const half_t* res, int ldres, half_t* out, int ldo, float alpha = 1.f, const VtOut* vt = nullptr) {
+  GemmP p; gemm_defaults(p);
+  p.x1 = a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
+  p.w = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = res; p.ldres = ldres; p.alpha = alpha;
+  p.out = out; p.ldo = ldo;
+  if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
+  c->ctr.executed_gemm_flops += 2.0 * M * N * K;
+  if (c->dry) return 0;
+  return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
+}
+
+// ResnetBlock2D.forward (my_diffusers/models/resnet.py:331-365); x2 = skip tensor concatenated on the channel axis
+static int resnet_fwd(pnpi_ctx* c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, int B, int H, int W, int G,
+                      float eps, half_t* out) {
+  const size_t mk = c->temp.mark();
+  const int HW = H * W;
+  const size_t M = (size_t)B * HW;
+  half_t* t1 = talloc(c, M * r.cin);
+  CK(op_gn(c, x1, x2, C1, C2, B, HW, r.n1, G, eps, 1, t1));
+  half_t* t2 = talloc(c, M * r.cout);
+  const float* b1 = r.temb_off >= 0 ? c->bias_eff + r.temb_off : r.c1.b;
+  CK(op_conv(c, t1, r.cin, nullptr, 0, B, H, W, r.c1, 1, 1, 0, b1, nullptr, t2, H, W));
+  half_t* t3 = talloc(c, M * r.cout);
+  CK(op_gn(c, t2, nullptr, r.cout, 0, B, HW, r.n2, G, eps, 1, t3));
+  const half_t* sc = x1;
+  if (r.has_sc) {
+    half_t* s = talloc(c, M * r.cout);
+    CK(op_conv(c, x1, C1, x2, C2, B, H, W, r.sc, 1, 0, 0, r.sc.b, nullptr, s, H, W));
+    sc = s;
+  }
+  CK(op_conv(c, t3, r.cout, nullptr, 0, B, H, W, r.c2, 1, 1, 0, r.c2.b, sc, out, H, W));
+  c->temp.release(mk);
+  return 0;
+}
+
+// SpatialTransformer + BasicTransformerBlock (my_diffusers/models/attention.py:140-200) with the hooked attention of
+// models/p2p/attention_control.py:20-47 and the controller semantics of :178-190, :269-282 fused into the kernels.
+static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, int B, int H, int W, const half_t* ctx16,
+                           bool use_ctrl, int cur_step, half_t* out) {
+  const pnpi_model_config& g = c->cfg;
+  const size_t mk = c->temp.mark();
+  const int C = t.C, N = H * W, M = B * N, hd = t.heads * t.Dp, X = g.cross_dim, T = g.ctx_len;
+  const float scale = 1.0f / sqrtf((float)t.dh);
+  CtrlDev& cd = c->cd;
+  const bool edit = use_ctrl && cd.any_edit;
+
+  half_t* g0 = talloc(c, (size_t)M * C);
+  CK(op_gn(c, x, nullptr, C, 0, B, N, t.gn, g.norm_groups, 1e-6f, 0, g0));
+  half_t* hs = talloc(c, (size_t)M * C);
+  CK(op_conv(c, g0, C, nullptr, 0, B, H, W, t.proj_in, 1, 0, 0, t.proj_in.b, nullptr, hs, H, W));
+
+  // ---- self-attention
+  half_t* n1 = talloc(c, (size_t)M * C);
+  if (!c->dry) CK(launch_layernorm(hs, M, C, 1e-5f, t.ln1.g, t.ln1.b, n1, c->st));
+  half_t* qk = talloc(c, (size_t)M * 2 * hd);
+  const int ldv = round_up_i(N, 8);
+  half_t* vt = talloc(c, (size_t)B * hd * ldv);
+  {
+    VtOut v; v.outT = vt; v.col0 = 2 * hd; v.ld = ldv; v.f32 = 0; v.rpb = N;
+    CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qk, 2 * hd, 1.f, &v));
+  }
+  half_t* ao = talloc(c, (size_t)M * C);
+  {
+    AttnP a; a.q = qk; a.ldq = 2 * hd; a.q_off = 0; a.k = qk; a.ldk = 2 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv;
+    a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
+    const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
+    a.rows = rep ? cd.rows_rep : cd.rows_id; a.nrows = B;
+    c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
+    if (!c->dry) CK(launch_attn_flash(a, c->st));
+  }
+  half_t* hs1 = talloc(c, (size_t)M * C);
+  CK(op_gemm(c, ao, C, M, C, t.o1.w, C, C, t.o1.b, hs, C, hs1, C));
+
+  // ---- cross-attention
+  half_t* n2 = talloc(c, (size_t)M * C);
+  if (!c->dry) CK(launch_layernorm(hs1, M, C, 1e-5f, t.ln2.g, t.ln2.b, n2, c->st));
+  half_t* q2 = talloc(c, (size_t)M * hd);
+  CK(op_gemm(c, n2, C, M, C, t.w_q2, C, hd, nullptr, nullptr, 0, q2, hd));
+  half_t* k2 = talloc(c, (size_t)B * T * hd);
+  const int ldv2 = round_up_i(T, 8);
+  half_t* vt2 = talloc(c, (size_t)B * hd * ldv2);
+  {
+    VtOut v; v.outT = vt2; v.col0 = hd; v.ld = ldv2; v.f32 = 0; v.rpb = T;
+    CK(op_gemm(c, ctx16, X, B * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v));
+  }
+  half_t* ao2 = talloc(c, (size_t)M * C);
+  {
+    AttnP a; a.q = q2; a.ldq = hd; a.q_off = 0; a.k = k2; a.ldk = hd; a.k_off = 0; a.vt = vt2; a.ldv = ldv2;
+    a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
+    a.rows = edit ? cd.rows_plain : cd.rows_id; a.nrows = edit ? cd.n_plain : B;
+    c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * 96 * t.Dp;
+    if (!c->dry) CK(launch_attn_flash(a, c->st));
+    if (edit && !c->dry) {
+      CrossEditP e; e.q = q2; e.ldq = hd; e.q_off = 0; e.k = k2; e.ldk = hd; e.k_off = 0; e.vt = vt2; e.ldv = ldv2;
+      e.o = ao2; e.ldo = C; e.heads = t.heads; e.Nq = N; e.Nk = T; e.Dp = t.Dp; e.dh = t.dh; e.scale = scale;
+      e.pairs = cd.pairs; e.npairs = cd.npairs; e.mmatT = cd.mmatT;
+      int srow = cur_step < cd.n_alpha_rows ? cur_step : cd.n_alpha_rows - 1;
+      e.c1 = cd.coef + ((size_t)srow * 2 + 0) * cd.npairs * 96;
+      e.c2 = cd.coef + ((size_t)srow * 2 + 1) * cd.npairs * 96;
+      const bool lb = cd.lb_any && t.lb_slot0 >= 0 && N == c->unet.lb_tokens;
+      e.lb_alpha = lb ? cd.lb_alpha : nullptr;
+      e.lb_acc = lb ? cd.lb_acc : nullptr;
+      e.lb_slot0 = t.lb_slot0; e.lb_nslots = c->unet.lb_nslots;
+      CK(launch_attn_cross_edit(e, c->st));
+    }
+  }
+  half_t* hs2 = talloc(c, (size_t)M * C);
+  CK(op_gemm(c, ao2, C, M, C, t.o2.w, C, C, t.o2.b, hs1, C, hs2, C));
+
+  // ---- GEGLU feed-forward
+  half_t* n3 = talloc(c, (size_t)M * C);
+  if (!c->dry) CK(launch_layernorm(hs2, M, C, 1e-5f, t.ln3.g, t.ln3.b, n3, c->st));
+  half_t* f1 = talloc(c, (size_t)M * 8 * C);
+  CK(op_gemm(c, n3, C, M, C, t.ff1.w, C, 8 * C, t.ff1.b, nullptr, 0, f1, 8 * C));
+  half_t* f2 = talloc(c, (size_t)M * 4 * C);
+  if (!c->dry) CK(launch_geglu(f1, M, 4 * C, f2, c->st));
+  half_t* hs3 = talloc(c, (size_t)M * C);
+  CK(op_gemm(c, f2, 4 * C, M, 4 * C, t.ff2.w, 4 * C, C, t.ff2.b, hs2, C, hs3, C));
+  CK(op_conv(c, hs3, C, nullptr, 0, B, H, W, t.proj_out, 1, 0, 0, t.proj_out.b, x, out, H, W));
+  c->temp.release(mk);
+  return 0;
+}
+
+// UNet2DConditionModel.forward (my_diffusers/models/unet_2d_condition.py:189-273)
+static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const float* context, bool use_ctrl, int cur_step,
+                    float* eps_out) {
+  const pnpi_model_config& g = c->cfg;
+  const UNetW& u = c->unet;
+  if (rows <= 0 || rows > c->max_rows) return fail(c, PNPI_EINVAL, "unet rows out of range (max_unet_rows)");
+  if (t < 0 || t >= g.n_train_timesteps) return fail(c, PNPI_EINVAL, "timestep out of range");
+  c->persist.reset(); c->temp.reset();
+  const int S = g.sample_size, n = g.n_blocks, C0 = g.block_out_channels[0], TE = 4 * C0, G = g.norm_groups;
+  const int B = rows;
+  const float eps = 1e-5f;
+  half_t* x0 = palloc(c, (size_t)B * S * S * 8);
+  half_t* ctx16 = palloc(c, (size_t)B * g.ctx_len * g.cross_dim);
+  if (!c->dry) {
+    CK(launch_nchw_f32_to_nhwc_f16(latents, B, g.in_channels, S * S, 8, x0, c->st));
+    CK(launch_f32_to_f16(context, (size_t)B * g.ctx_len * g.cross_dim, ctx16, c->st));
+    CK(launch_gemv(c->temb_table + (size_t)t * C0, C0, u.t1.w, TE, u.t1.b, nullptr, 0, c->temb_h, c->st));
+    CK(launch_gemv(c->temb_h, TE, u.t2.w, TE, u.t2.b, nullptr, 1, c->temb_emb, c->st));
+    CK(launch_gemv(c->temb_emb, TE, u.temb_w, u.temb_total, u.temb_b, u.conv1_b, 1, c->bias_eff, c->st));
+  }
+  struct Act { half_t* p; int C, H; };
+  std::vector<Act> skips;
+  int H = S;
+  half_t* h = palloc(c, (size_t)B * H * H * C0);
+  CK(op_conv(c, x0, 8, nullptr, 0, B, H, H, u.conv_in, 1, 1, 0, u.conv_in.b, nullptr, h, H, H));
+  int ch = C0;
+  skips.push_back({h, ch, H});
+  for (int i = 0; i < n; ++i) {
+    const int oc = g.block_out_channels[i];
+    for (int j = 0; j < g.layers_per_block; ++j) {
+      half_t* o = palloc(c, (size_t)B * H * H * oc);
+      CKP(resnet_fwd(c, u.down_res[i][j], h, ch, nullptr, 0, B, H, H, G, eps, o));
+      h = o; ch = oc;
+      if (g.block_has_attn[i]) {
+        half_t* o2 = palloc(c, (size_t)B * H * H * oc);
+        CKP(transformer_fwd(c, u.down_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2));
+        h = o2;
+      }
+      skips.push_back({h, ch, H});
+    }
+    if (i != n - 1) {
+      const int Ho = H / 2;
+      half_t* o = palloc(c, (size_t)B * Ho * Ho * oc);
+      CK(op_conv(c, h, ch, nullptr, 0, B, H, H, u.down_samp[i], 2, 1, 0, u.down_samp[i].b, nullptr, o, Ho, Ho));
+      h = o; H = Ho;
+      skips.push_back({h, ch, H});
+    }
+  }
+  {
+    half_t* o = palloc(c, (size_t)B * H * H * ch);
+    CKP(resnet_fwd(c, u.mid_res[0], h, ch, nullptr, 0, B, H, H, G, eps, o));
+    half_t* o2 = palloc(c, (size_t)B * H * H * ch);
+    CKP(transformer_fwd(c, u.mid_attn, o, B, H, H, ctx16, use_ctrl, cur_step, o2));
+    half_t* o3 = palloc(c, (size_t)B * H * H * ch);
+    CKP(resnet_fwd(c, u.mid_res[1], o2, ch, nullptr, 0, B, H, H, G, eps, o3));
+    h = o3;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int oc = g.block_out_channels[n - 1 - i];
+    for (int j = 0; j <= g.layers_per_block; ++j) {
+      Act s = skips.back(); skips.pop_back();
+      half_t* o = palloc(c, (size_t)B * H * H * oc);
+      CKP(resnet_fwd(c, u.up_res[i][j], h, ch, s.p, s.C, B, H, H, G, eps, o));
+      h = o; ch = oc;
+      if (g.block_has_attn[n - 1 - i]) {
+        half_t* o2 = palloc(c, (size_t)B * H * H * oc);
+        CKP(transformer_fwd(c, u.up_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2));
+        h = o2;
+      }
+    }
+    if (i != n - 1) {
+      const int Ho = H * 2;
+      half_t* o = palloc(c, (size_t)B * Ho * Ho * oc);
+      CK(op_conv(c, h, ch, nullptr, 0, B, H, H, u.up_samp[i], 1, 1, 1, u.up_samp[i].b, nullptr, o, Ho, Ho));
+      h = o; H = Ho;
+    }
+  }
+  half_t* gno = palloc(c, (size_t)B * H * H * ch);
+  CK(op_gn(c, h, nullptr, ch, 0, B, H * H, u.norm_out, G, eps, 1, gno));
+  {
+    VtOut v; v.outT = eps_out; v.col0 = 0; v.ld = H * H; v.f32 = 1; v.rpb = H * H;
+    CK(op_conv(c, gno, ch, nullptr, 0, B, H, H, u.conv_out, 1, 1, 0, u.conv_out.b, nullptr, nullptr, H, H, -1, &v));
+  }
+  c->ctr.unet_calls += c->dry ? 0 : 1;
+  c->ctr.unet_sample_forwards += c->dry ? 0 : rows;
+  if (c->persist.overflow || c->temp.overflow) return fail(c, PNPI_ENOMEM, "workspace overflow");
+  return 0;
+}
+
+// AttentionBlock.forward (my_diffusers/models/attention.py:54-92): single head, scores materialised per image (VAE only)
+static int vae_attn_fwd(pnpi_ctx* c, const VaeAttnW& a, const half_t* x, int B, int H, int W, half_t* out) {
+  const size_t mk = c->temp.mark();
+  const int C = a.C, N = H * W, M = B * N;
+  half_t* g0 = talloc(c, (size_t)M * C);
+  CK(op_gn(c, x, nullptr, C, 0, B, N, a.gn, c->cfg.vae_norm_groups, 1e-6f, 0, g0));
+  half_t* qk = talloc(c, (size_t)M * 2 * C);
+  const int ldv = round_up_i(N, 8);
+  half_t* vt = talloc(c, (size_t)B * C * ldv);
+  {
+    VtOut v; v.outT = vt; v.col0 = 2 * C; v.ld = ldv; v.f32 = 0; v.rpb = N;
+    CK(op_gemm(c, g0, C, M, C, a.w_qkv, C, 3 * C, a.b_qkv, nullptr, 0, qk, 2 * C, 1.f, &v));
+  }
+  half_t* ao = talloc(c, (size_t)M * C);
+  half_t* sc = talloc(c, (size_t)N * ldv);
+  const float alpha = 1.0f / sqrtf((float)C);
+  for (int b = 0; b < B; ++b) {
+    const half_t* qb = qk + (size_t)b * N * 2 * C;
+    CK(op_gemm(c, qb, 2 * C, N, C, qb + C, 2 * C, N, nullptr, nullptr, 0, sc, ldv, alpha));
+    if (!c->dry) CK(launch_softmax_rows(sc, N, N, ldv, c->st));
+    CK(op_gemm(c, sc, ldv, N, N, vt + (size_t)b * C * ldv, ldv, C, nullptr, nullptr, 0, ao + (size_t)b * N * C, C));
+  }
+  CK(op_gemm(c, ao, C, M, C, a.proj.w, C, C, a.proj.b, x, C, out, C));
+  c->temp.release(mk);
+  return 0;
+}
+
+// Encoder.forward + quant_conv, posterior mean (my_diffusers/models/vae.py:113-130, 552-560, 329-336). x: NHWC fp16, 8-ch padded.
+static int vae_encode_fwd(pnpi_ctx* c, const half_t* x, int B, int H, int W, float* mean_out) {
+  const pnpi_model_config& g = c->cfg; const VaeW& v = c->vae;
+  const int vn = g.vae_n_blocks, G = g.vae_norm_groups, L = g.vae_latent_channels;
+  const float eps = 1e-6f;
+  int ch = g.vae_block_out_channels[0];
+  half_t* h = palloc(c, (size_t)B * H * W * ch);
+  CK(op_conv(c, x, 8, nullptr, 0, B, H, W, v.e_conv_in, 1, 1, 0, v.e_conv_in.b, nullptr, h, H, W));
+  for (int i = 0; i < vn; ++i) {
+    const int oc = g.vae_block_out_channels[i];
+    for (int j = 0; j < g.vae_layers_per_block; ++j) {
+      half_t* o = palloc(c, (size_t)B * H * W * oc);
+      CKP(resnet_fwd(c, v.e_res[i][j], h, ch, nullptr, 0, B, H, W, G, eps, o));
+      h = o; ch = oc;
+    }
+    if (i != vn - 1) {
+      // Downsample2D with padding=0: F.pad(x, (0,1,0,1)) then stride-2 conv (resnet.py:89-95)
+      const int Ho = H / 2, Wo = W / 2;
+      half_t* o = palloc(c, (size_t)B * Ho * Wo * oc);
+      CK(op_conv(c, h, ch, nullptr, 0, B, H, W, v.e_down[i], 2, 0, 0, v.e_down[i].b, nullptr, o, Ho, Wo));
+      h = o; H = Ho; W = Wo;
+    }
+  }
+  half_t* m0 = palloc(c, (size_t)B * H * W * ch);
+  CKP(resnet_fwd(c, v.e_mid[0], h, ch, nullptr, 0, B, H, W, G, eps, m0));
+  half_t* m1 = palloc(c, (size_t)B * H * W * ch);
+  CKP(vae_attn_fwd(c, v.e_attn, m0, B, H, W, m1));
+  half_t* m2 = palloc(c, (size_t)B * H * W * ch);
+  CKP(resnet_fwd(c, v.e_mid[1], m1, ch, nullptr, 0, B, H, W, G, eps, m2));
+  half_t* gno = palloc(c, (size_t)B * H * W * ch);
+  CK(op_gn(c, m2, nullptr, ch, 0, B, H * W, v.e_norm_out, G, eps, 1, gno));
+  half_t* mo = palloc(c, (size_t)B * H * W * 8);
+  CK(op_conv(c, gno, ch, nullptr, 0, B, H, W, v.e_conv_out, 1, 1, 0, v.e_conv_out.b, nullptr, mo, H, W, 8));
+  {
+    VtOut vv; vv.outT = mean_out; vv.col0 = 0; vv.ld = H * W; vv.f32 = 1; vv.rpb = H * W;
+    CK(op_conv(c, mo, 8, nullptr, 0, B, H, W, v.quant, 1, 0, 0, v.quant.b, nullptr, nullptr, H, W, L, &vv));
+  }
+  return 0;
+}
+
+// post_quant_conv + Decoder.forward (vae.py:562-566, 191-209). z: NHWC fp16, 8-ch padded. out: fp32 NCHW.
+static int vae_decode_fwd(pnpi_ctx* c, const half_t* z, int B, int H, int W, float* out_nchw) {
+  const pnpi_model_config& g = c->cfg; const VaeW& v = c->vae;
+  const int vn = g.vae_n_blocks, G = g.vae_norm_groups;
+  const float eps = 1e-6f;
+  half_t* pq = palloc(c, (size_t)B * H * W * 8);
+  CK(op_conv(c, z, 8, nullptr, 0, B, H, W, v.post_quant, 1, 0, 0, v.post_quant.b, nullptr, pq, H, W, 8));
+  int ch = g.vae_block_out_channels[vn - 1];
+  half_t* h = palloc(c, (size_t)B * H * W * ch);
+  CK(op_conv(c, pq, 8, nullptr, 0, B, H, W, v.d_conv_in, 1, 1, 0, v.d_conv_in.b, nullptr, h, H, W));
+  half_t* m0 = palloc(c, (size_t)B * H * W * ch);
+  CKP(resnet_fwd(c, v.d_mid[0], h, ch, nullptr, 0, B, H, W, G, eps, m0));
+  half_t* m1 = palloc(c, (size_t)B * H * W * ch);
+  CKP(vae_attn_fwd(c, v.d_attn, m0, B, H, W, m1));
+  half_t* m2 = palloc(c, (size_t)B * H * W * ch);
+  CKP(resnet_fwd(c, v.d_mid[1], m1, ch, nullptr, 0, B, H, W, G, eps, m2));
+  h = m2;
+  for (int i = 0; i < vn; ++i) {
+    const int oc = g.vae_block_out_channels[vn - 1 - i];
+    for (int j = 0; j <= g.vae_layers_per_block; ++j) {
+      half_t* o = palloc(c, (size_t)B * H * W * oc);
+      CKP(resnet_fwd(c, v.d_res[i][j], h, ch, nullptr, 0, B, H, W, G, eps, o));
+      h = o; ch = oc;
+    }
+    if (i != vn - 1) {
+      const int Ho = H * 2, Wo = W * 2;
+      half_t* o = palloc(c, (size_t)B * Ho * Wo * oc);
+      CK(op_conv(c, h, ch, nullptr, 0, B, H, W, v.d_up[i], 1, 1, 1, v.d_up[i].b, nullptr, o, Ho, Wo));
+      h = o; H = Ho; W = Wo;
+    }
+  }
+  half_t* gno = palloc(c, (size_t)B * H * W * ch);
+  CK(op_gn(c, h, nullptr, ch, 0, B, H * W, v.d_norm_out, G, eps, 1, gno));
+  {
+    VtOut vv; vv.outT = out_nchw; vv.col0 = 0; vv.ld = H * W; vv.f32 = 1; vv.rpb = H * W;
+    CK(op_conv(c, gno, ch, nullptr, 0, B, H, W, v.d_conv_out, 1, 1, 0, v.d_conv_out.b, nullptr, nullptr, H, W, -1, &vv));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- controller tables
+static float* misc_f(pnpi_ctx* c, size_t n) { return (float*)c->ctrl_arena.alloc(n * sizeof(float)); }
+
+static int upload(pnpi_ctx* c, void* dst, const void* src, size_t bytes) {
+  CKH(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->st));
+  // the host staging vectors are reused by the caller: make the copy complete before returning
+  CKH(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+// Build the device-side tables for `rows` UNet rows (rows_per_image = 4 when controllers are active).
+static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows) {
+  CtrlDev& cd = c->cd;
+  c->ctrl_arena.reset();
+  cd = CtrlDev();
+  cd.nimg = nimg;
+  std::vector<int> id(rows * 4), rep(rows * 4), plain, pairs;
+  for (int r = 0; r < rows; ++r) { id[r * 4] = r; id[r * 4 + 1] = r; id[r * 4 + 2] = r; id[r * 4 + 3] = r; }
+  rep = id;
+  const int T = c->cfg.ctx_len;
+  if (T > 96) return fail(c, PNPI_ESHAPE, "ctx_len > 96 unsupported by the cross-attention edit kernel");
+  std::vector<int> edit_img;
+  if (cds) {
+    if (rows != nimg * 4) return fail(c, PNPI_EINVAL, "controllers need rows == 4 * nimg");
+    for (int i = 0; i < nimg; ++i) if (cds[i].kind == 1) edit_img.push_back(i);
+  }
+  cd.any_edit = !edit_img.empty();
+  cd.npairs = (int)edit_img.size();
+  std::vector<bool> is_pair_row(rows, false);
+  for (int i : edit_img) {
+    int src = i * 4 + 2, tgt = i * 4 + 3;
+    rep[tgt * 4 + 1] = src; rep[tgt * 4 + 2] = src;  // q and k of the target row come from the source row
+    pairs.push_back(src); pairs.push_back(tgt);
+    is_pair_row[src] = is_pair_row[tgt] = true;
+    cd.pair_img.push_back(i);
+  }
+  for (int r = 0; r < rows; ++r) if (!is_pair_row[r]) { plain.push_back(r); plain.push_back(r); plain.push_back(r); plain.push_back(r); }
+  cd.n_plain = (int)plain.size() / 4;
+  cd.rows_id = (int*)c->ctrl_arena.alloc(id.size() * sizeof(int));
+  cd.rows_rep = (int*)c->ctrl_arena.alloc(rep.size() * sizeof(int));
+  CKP(upload(c, cd.rows_id, id.data(), id.size() * sizeof(int)));
+  CKP(upload(c, cd.rows_rep, rep.data(), rep.size() * sizeof(int)));
+  if (!plain.empty()) {
+    cd.rows_plain = (int*)c->ctrl_arena.alloc(plain.size() * sizeof(int));
+    CKP(upload(c, cd.rows_plain, plain.data(), plain.size() * sizeof(int)));
+  }
+  if (!cd.any_edit) return 0;
+  cd.pairs = (int*)c->ctrl_arena.alloc(pairs.size() * sizeof(int));
+  CKP(upload(c, cd.pairs, pairs.data(), pairs.size() * sizeof(int)));
+  const pnpi_ctrl_desc& d0 = cds[edit_img[0]];
+  cd.n_alpha_rows = d0.n_alpha_rows;
+  cd.self_lo = d0.self_replace_lo; cd.self_hi = d0.self_replace_hi; cd.self_max_tokens = d0.self_replace_max_tokens;
+  const int P = cd.npairs;
+  std::vector<half_t> mm((size_t)P * 96 * 96, (half_t)0.f);
+  std::vector<float> coef((size_t)cd.n_alpha_rows * 2 * P * 96, 0.f), lba((size_t)P * 2 * 96, 0.f);
+  for (int pi = 0; pi < P; ++pi) {
+    const pnpi_ctrl_desc& d = cds[edit_img[pi]];
+    if (d.n_alpha_rows != cd.n_alpha_rows || d.self_replace_lo != cd.self_lo || d.self_replace_hi != cd.self_hi ||
+        d.self_replace_max_tokens != cd.self_max_tokens)
+      return fail(c, PNPI_EINVAL, "all controllers of one batch must share the step schedule");
+    if (!d.cross_alpha_host || !d.mapper_host || !d.alphas_host || !d.equalizer_host)
+      return fail(c, PNPI_EINVAL, "controller tables missing");
+    for (int w = 0; w < T; ++w)
+      for (int j = 0; j < T; ++j) mm[((size_t)pi * 96 + j) * 96 + w] = (half_t)d.mapper_host[w * T + j];
+    for (int s = 0; s < cd.n_alpha_rows; ++s)
+      for (int j = 0; j < T; ++j) {
+        float a = d.cross_alpha_host[s * T + j], eq = d.equalizer_host[j], al = d.alphas_host[j];
+        coef[(((size_t)s * 2 + 0) * P + pi) * 96 + j] = a * eq * al;
+        coef[(((size_t)s * 2 + 1) * P + pi) * 96 + j] = a * eq * (1.f - al) + (1.f - a);
+      }
+    cd.lb_enabled.push_back(d.lb_enabled);
+    cd.lb_start.push_back(d.lb_start);
+    cd.lb_th.push_back(d.lb_threshold);
+    if (d.lb_enabled) {
+      if (!d.lb_alpha_host) return fail(c, PNPI_EINVAL, "lb_alpha missing");
+      if (c->unet.lb_nslots == 0) return fail(c, PNPI_ESHAPE, "LocalBlend needs the five 16x16 cross-attention maps (latent 64x64 layout)");
+      cd.lb_any = 1;
+      for (int w = 0; w < 2; ++w)
+        for (int j = 0; j < T; ++j) lba[((size_t)pi * 2 + w) * 96 + j] = d.lb_alpha_host[w * T + j];
+    }
+  }
+  cd.mmatT = (half_t*)c->ctrl_arena.alloc(mm.size() * sizeof(half_t));
+  cd.coef = misc_f(c, coef.size());
+  CKP(upload(c, cd.mmatT, mm.data(), mm.size() * sizeof(half_t)));
+  CKP(upload(c, cd.coef, coef.data(), coef.size() * sizeof(float)));
+  if (cd.lb_any) {
+    cd.lb_alpha = misc_f(c, lba.size());
+    CKP(upload(c, cd.lb_alpha, lba.data(), lba.size() * sizeof(float)));
+    size_t nacc = (size_t)P * c->unet.lb_nslots * 2 * c->unet.lb_tokens;
+    cd.lb_acc = misc_f(c, nacc);
+    CKH(hipMemsetAsync(cd.lb_acc, 0, nacc * sizeof(float), c->st));
+  }
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "controller arena overflow");
+  return 0;
+}
+
+static int apply_local_blend(pnpi_ctx* c, float* latents /*[nimg][2][E]*/, int step_index) {
+  CtrlDev& cd = c->cd;
+  if (!cd.lb_any) return 0;
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
+  const int mhw = (int)lroundf(sqrtf((float)c->unet.lb_tokens));
+  for (int pi = 0; pi < cd.npairs; ++pi) {
+    if (!cd.lb_enabled[pi]) continue;
+    if (step_index + 1 <= cd.lb_start[pi]) continue;   // LocalBlend.counter > start_blend (attention_control.py:108-110)
+    const float* acc = cd.lb_acc + (size_t)pi * c->unet.lb_nslots * 2 * c->unet.lb_tokens;
+    CK(launch_local_blend(acc, c->unet.lb_nslots, mhw, g.sample_size, g.in_channels, cd.lb_th[pi],
+                          latents + (size_t)cd.pair_img[pi] * 2 * E, 1, c->st));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+void pnpi_config_sd1(pnpi_model_config* g) {
+  memset(g, 0, sizeof(*g));
+  g->in_channels = 4; g->out_channels = 4; g->n_blocks = 4;
+  int boc[4] = {320, 640, 1280, 1280}, att[4] = {1, 1, 1, 0}, vb[4] = {128, 256, 512, 512};
+  for (int i = 0; i < 4; ++i) { g->block_out_channels[i] = boc[i]; g->block_has_attn[i] = att[i]; g->vae_block_out_channels[i] = vb[i]; }
+  g->layers_per_block = 2; g->heads = 8; g->cross_dim = 768; g->ctx_len = 77; g->sample_size = 64; g->norm_groups = 32;
+  g->n_train_timesteps = 1000; g->vae_in_channels = 3; g->vae_latent_channels = 4; g->vae_n_blocks = 4;
+  g->vae_layers_per_block = 2; g->vae_norm_groups = 32;
+}
+
+const char* pnpi_last_error(const pnpi_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+static int validate_config(pnpi_ctx* c) {
+  const pnpi_model_config& g = c->cfg;
+  if (g.n_blocks < 2 || g.n_blocks > 4 || g.vae_n_blocks < 2 || g.vae_n_blocks > 4) return fail(c, PNPI_ESHAPE, "n_blocks must be 2..4");
+  for (int i = 0; i < g.n_blocks; ++i) {
+    int ch = g.block_out_channels[i];
+    if (ch % g.norm_groups || ch % 8 || ch % g.heads) return fail(c, PNPI_ESHAPE, "block_out_channels must divide by groups, heads and 8");
+    int dh = ch / g.heads;
+    if (g.block_has_attn[i] && (dh % 4 || dh > 160)) return fail(c, PNPI_ESHAPE, "head dim must be a multiple of 4 and <= 160");
+  }
+  for (int i = 0; i < g.vae_n_blocks; ++i)
+    if (g.vae_block_out_channels[i] % g.vae_norm_groups || g.vae_block_out_channels[i] % 8) return fail(c, PNPI_ESHAPE, "vae channels");
+  if (g.cross_dim % 8 || g.ctx_len > 96 || g.in_channels > 8 || g.vae_latent_channels > 4 || g.vae_in_channels != 3)
+    return fail(c, PNPI_ESHAPE, "cross_dim/ctx_len/in_channels unsupported");
+  if (g.sample_size % (1 << (g.n_blocks - 1))) return fail(c, PNPI_ESHAPE, "sample_size must divide by 2^(n_blocks-1)");
+  if (g.block_out_channels[0] % 2) return fail(c, PNPI_ESHAPE, "C0 must be even");
+  return 0;
+}
+
+int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images) {
+  if (!out || !cfg) return PNPI_EINVAL;
+  pnpi_ctx* c = new pnpi_ctx();
+  *out = c;
+  c->cfg = *cfg; c->device = device; c->st = (hipStream_t)hip_stream; c->max_rows = max_unet_rows; c->max_vae = max_vae_images;
+  c->dry = true; c->sched_set = false; c->final_alpha = 0.f;
+  c->splitk_ws = nullptr; c->gn_partial = nullptr; c->temb_table = nullptr;
+  memset(&c->ctr, 0, sizeof(c->ctr));
+  CKP(validate_config(c));
+  CKH(hipSetDevice(device));
+  CK(igemm_init());
+  const pnpi_model_config& g = c->cfg;
+  // pass 1: measure the weight arena; pass 2: real pointers
+  build_model(c);
+  const size_t wbytes = align_up(c->warena.peak + 4096, 4096);
+  CKH(hipMalloc((void**)&c->warena.base, wbytes));
+  CKH(hipMemsetAsync(c->warena.base, 0, wbytes, c->st));
+  c->warena.cap = wbytes; c->warena.reset(); c->warena.peak = 0;
+  build_model(c);
+  // small persistent buffers
+  const int C0 = g.block_out_channels[0], TE = 4 * C0;
+  c->splitk_bytes = (size_t)96 << 20;
+  CKH(hipMalloc((void**)&c->splitk_ws, c->splitk_bytes));
+  size_t gnp = (size_t)(max_unet_rows > max_vae_images ? max_unet_rows : max_vae_images) * 128 * 64 * 2 * sizeof(float);
+  CKH(hipMalloc((void**)&c->gn_partial, gnp));
+  CKH(hipMalloc((void**)&c->temb_h, TE * sizeof(float)));
+  CKH(hipMalloc((void**)&c->temb_emb, TE * sizeof(float)));
+  CKH(hipMalloc((void**)&c->bias_eff, (size_t)c->unet.temb_total * sizeof(float)));
+  // sinusoidal timestep table, get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0), fp64 -> fp32
+  // (my_diffusers/models/embeddings.py:21-60)
+  {
+    const int half = C0 / 2;
+    std::vector<float> tab((size_t)g.n_train_timesteps * C0);
+    for (int t = 0; t < g.n_train_timesteps; ++t)
+      for (int i = 0; i < half; ++i) {
+        double e = exp(-log(10000.0) * (double)i / (double)half);
+        double a = (double)t * e;
+        tab[(size_t)t * C0 + i] = (float)cos(a);          // flipped: cos first
+        tab[(size_t)t * C0 + half + i] = (float)sin(a);
+      }
+    CKH(hipMalloc((void**)&c->temb_table, tab.size() * sizeof(float)));
+    CKH(hipMemcpy(c->temb_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // controller / loop arena
+  {
+    const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
+    size_t cap = ((size_t)8 << 20) + (size_t)max_unet_rows * E * sizeof(float) * 8 +
+                 (size_t)max_unet_rows * (96 * 96 * 2 + 64 * 2 * 96 * 4 * 2 + (size_t)c->unet.lb_nslots * 2 * c->unet.lb_tokens * 4);
+    CKH(hipMalloc((void**)&c->ctrl_arena.base, cap));
+    c->ctrl_arena.cap = cap;
+  }
+  // dry runs to size the activation workspaces
+  c->dry = true;
+  c->persist = Bump(); c->temp = Bump();
+  size_t ppeak = 0, tpeak = 0;
+  if (max_unet_rows > 0) {
+    int r = unet_fwd(c, nullptr, max_unet_rows, 0, nullptr, false, 0, nullptr);
+    if (r) return r;
+    ppeak = c->persist.peak; tpeak = c->temp.peak;
+  }
+  if (max_vae_images > 0) {
+    const int S = g.sample_size, F = 1 << (g.vae_n_blocks - 1);
+    c->persist.reset(); c->temp.reset(); c->persist.peak = 0; c->temp.peak = 0;
+    (void)palloc(c, (size_t)max_vae_images * S * F * S * F * 8);
+    int r = vae_encode_fwd(c, nullptr, max_vae_images, S * F, S * F, nullptr);
+    if (r) return r;
+    if (c->persist.peak > ppeak) ppeak = c->persist.peak;
+    if (c->temp.peak > tpeak) tpeak = c->temp.peak;
+    c->persist.reset(); c->temp.reset(); c->persist.peak = 0; c->temp.peak = 0;
+    (void)palloc(c, (size_t)max_vae_images * S * S * 8);
+    (void)c->persist.alloc((size_t)max_vae_images * 3 * S * F * S * F * sizeof(float));
+    r = vae_decode_fwd(c, nullptr, max_vae_images, S, S, nullptr);
+    if (r) return r;
+    if (c->persist.peak > ppeak) ppeak = c->persist.peak;
+    if (c->temp.peak > tpeak) tpeak = c->temp.peak;
+  }
+  ppeak = align_up(ppeak + (1 << 20), 4096); tpeak = align_up(tpeak + (1 << 20), 4096);
+  CKH(hipMalloc((void**)&c->persist.base, ppeak));
+  CKH(hipMalloc((void**)&c->temp.base, tpeak));
+  c->persist.cap = ppeak; c->temp.cap = tpeak; c->persist.reset(); c->temp.reset();
+  c->dry = false;
+  memset(&c->ctr, 0, sizeof(c->ctr));
+  // identity attention-row table for the controller-free path
+  CKP(setup_ctrl(c, nullptr, 0, max_unet_rows > 0 ? max_unet_rows : 1));
+  CKH(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+void pnpi_destroy(pnpi_ctx* c) {
+  if (!c) return;
+  (void)hipStreamSynchronize(c->st);
+  void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial,
+                  c->temb_table, c->temb_h, c->temb_emb, c->bias_eff};
+  for (void* b : bufs) (void)hipFree(b);
+  delete c;
+}
+
+int pnpi_load_weights(pnpi_ctx* c, const pnpi_named_tensor* ts, int n) {
+  if (!c || !ts) return PNPI_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    const pnpi_named_tensor& t = ts[i];
+    std::string name = t.name;
+    // diffusers 0.3-0.10 register the stride-2 conv twice ("conv" and "Conv2d_0"): accept either spelling
+    size_t pos = name.find(".downsamplers.0.Conv2d_0.");
+    if (pos != std::string::npos) name.replace(pos, strlen(".downsamplers.0.Conv2d_0."), ".downsamplers.0.conv.");
+    auto it = c->slots.find(name);
+    if (it == c->slots.end()) continue;  // unknown keys are ignored (e.g. buffers)
+    Slot& s = it->second;
+    size_t numel = 1;
+    for (int d = 0; d < t.ndim; ++d) numel *= (size_t)t.shape[d];
+    if (s.kind == 0) {
+      if (numel != (size_t)s.rows * s.cols * s.taps) { c->err = "shape mismatch for " + name; return PNPI_ESHAPE; }
+      CK(launch_repack_matrix(t.data, t.dtype, s.rows, s.cols, s.taps, (half_t*)s.dst, s.dst_ld, s.cin_pad, s.row0, s.dh, s.Dp, c->st));
+    } else {
+      if (numel != (size_t)s.n) { c->err = "shape mismatch for " + name; return PNPI_ESHAPE; }
+      CK(launch_repack_vec(t.data, t.dtype, s.n, (float*)s.dst, c->st));
+    }
+    s.loaded = true;
+  }
+  return 0;
+}
+
+int pnpi_missing_weights(const pnpi_ctx* c, char* names_out, size_t cap) {
+  int missing = 0;
+  size_t used = 0;
+  if (names_out && cap) names_out[0] = 0;
+  for (auto& kv : c->slots)
+    if (!kv.second.loaded) {
+      ++missing;
+      if (names_out && used + kv.first.size() + 2 < cap) {
+        memcpy(names_out + used, kv.first.c_str(), kv.first.size());
+        used += kv.first.size();
+        names_out[used++] = '\n';
+        names_out[used] = 0;
+      }
+    }
+  return missing;
+}
+
+int pnpi_weight_arena(pnpi_ctx* c, void** ptr, size_t* bytes) {
+  if (!c || !ptr || !bytes) return PNPI_EINVAL;
+  *ptr = c->warena.base; *bytes = c->warena.cap;
+  // after a broadcast every slot of the receiving ranks is populated
+  return 0;
+}
+
+int pnpi_mark_all_loaded(pnpi_ctx* c) {
+  for (auto& kv : c->slots) kv.second.loaded = true;
+  return 0;
+}
+
+int pnpi_set_scheduler(pnpi_ctx* c, const float* ac, int n_train, float final_alpha) {
+  if (!c || !ac || n_train != c->cfg.n_train_timesteps) return PNPI_EINVAL;
+  c->ac.assign(ac, ac + n_train);
+  c->final_alpha = final_alpha;
+  c->sched_set = true;
+  return 0;
+}
+
+int pnpi_get_counters(const pnpi_ctx* c, pnpi_counters* out) { if (!c || !out) return PNPI_EINVAL; *out = c->ctr; return 0; }
+int pnpi_reset_counters(pnpi_ctx* c) { if (!c) return PNPI_EINVAL; memset(&c->ctr, 0, sizeof(c->ctr)); return 0; }
+
+static int check_ready(pnpi_ctx* c) {
+  for (auto& kv : c->slots) if (!kv.second.loaded) { c->err = "weights not loaded: " + kv.first; return PNPI_ESTATE; }
+  return 0;
+}
+
+int pnpi_unet_forward(pnpi_ctx* c, const float* latents, int rows, int rows_per_image, int t, const float* context,
+                      const pnpi_ctrl_desc* ctrl_host, int cur_step, float* eps_out) {
+  if (!c || !latents || !context || !eps_out) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  bool use_ctrl = false;
+  if (ctrl_host) {
+    if (rows_per_image != 4 || rows % 4) return fail(c, PNPI_EINVAL, "controllers need rows_per_image == 4");
+    if (cur_step == 0 || c->cd.nimg != rows / 4) CKP(setup_ctrl(c, ctrl_host, rows / 4, rows));
+    use_ctrl = true;
+  } else if (c->cd.any_edit || c->cd.nimg != 0) {
+    CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  }
+  return unet_fwd(c, latents, rows, t, context, use_ctrl, cur_step, eps_out);
+}
+
+/* LocalBlend step_callback for level-1 drivers (attention_control.py:253-256): latents [nimg][2][4][h][w] in place */
+int pnpi_local_blend(pnpi_ctx* c, float* latents, int nimg, int step_index) {
+  if (!c || !latents || nimg != c->cd.nimg) return PNPI_EINVAL;
+  return apply_local_blend(c, latents, step_index);
+}
+
+int pnpi_vae_encode(pnpi_ctx* c, const float* x, int n, int height, int width, float* mean_out) {
+  if (!c || !x || !mean_out || n <= 0 || n > c->max_vae) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  c->persist.reset(); c->temp.reset();
+  half_t* xin = palloc(c, (size_t)n * height * width * 8);
+  CK(launch_nchw_f32_to_nhwc_f16(x, n, 3, height * width, 8, xin, c->st));
+  CKP(vae_encode_fwd(c, xin, n, height, width, mean_out));
+  c->ctr.vae_encodes += n;
+  if (c->persist.overflow || c->temp.overflow) return fail(c, PNPI_ENOMEM, "workspace overflow (vae encode)");
+  return 0;
+}
+
+int pnpi_image2latent(pnpi_ctx* c, const uint8_t* img, int n, int height, int width, float* z_out) {
+  if (!c || !img || !z_out || n <= 0 || n > c->max_vae) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  c->persist.reset(); c->temp.reset();
+  half_t* xin = palloc(c, (size_t)n * height * width * 8);
+  CK(launch_img_u8_to_nhwc(img, n, height * width, 8, xin, c->st));
+  CKP(vae_encode_fwd(c, xin, n, height, width, z_out));
+  const int F = 1 << (c->cfg.vae_n_blocks - 1);
+  size_t ne = (size_t)n * c->cfg.vae_latent_channels * (height / F) * (width / F);
+  CK(launch_scale_f32(z_out, ne, 0.18215f, z_out, c->st));
+  c->ctr.vae_encodes += n;
+  if (c->persist.overflow || c->temp.overflow) return fail(c, PNPI_ENOMEM, "workspace overflow (vae encode)");
+  return 0;
+}
+
+static int decode_common(pnpi_ctx* c, const float* z, int n, int lh, int lw, float zscale, float* sample_out, uint8_t* u8_out) {
+  CKP(check_ready(c));
+  c->persist.reset(); c->temp.reset();
+  const int L = c->cfg.vae_latent_channels, F = 1 << (c->cfg.vae_n_blocks - 1);
+  const float* zin = z;
+  if (zscale != 1.0f) {
+    float* zs = (float*)c->persist.alloc((size_t)n * L * lh * lw * sizeof(float));
+    CK(launch_scale_f32(z, (size_t)n * L * lh * lw, zscale, zs, c->st));
+    zin = zs;
+  }
+  half_t* z16 = palloc(c, (size_t)n * lh * lw * 8);
+  CK(launch_nchw_f32_to_nhwc_f16(zin, n, L, lh * lw, 8, z16, c->st));
+  float* dst = sample_out;
+  if (!dst) dst = (float*)c->persist.alloc((size_t)n * 3 * lh * F * lw * F * sizeof(float));
+  CKP(vae_decode_fwd(c, z16, n, lh, lw, dst));
+  if (u8_out) CK(launch_dec_to_u8(dst, n, lh * F * lw * F, u8_out, c->st));
+  c->ctr.vae_decodes += n;
+  if (c->persist.overflow || c->temp.overflow) return fail(c, PNPI_ENOMEM, "workspace overflow (vae decode)");
+  return 0;
+}
+
+int pnpi_vae_decode(pnpi_ctx* c, const float* z, int n, int lh, int lw, float* sample_out) {
+  if (!c || !z || !sample_out || n <= 0 || n > c->max_vae) return PNPI_EINVAL;
+  return decode_common(c, z, n, lh, lw, 1.0f, sample_out, nullptr);
+}
+int pnpi_latent2image(pnpi_ctx* c, const float* z, int n, int lh, int lw, uint8_t* img_out) {
+  if (!c || !z || !img_out || n <= 0 || n > c->max_vae) return PNPI_EINVAL;
+  // utils/utils.py:60: latents = 1 / 0.18215 * latents  (python float 1/0.18215 rounded to fp32 by the tensor multiply)
+  return decode_common(c, z, n, lh, lw, (float)(1.0 / 0.18215), nullptr, img_out);
+}
+
+static int alphas_for(pnpi_ctx* c, int t, int ratio, bool forward, float* a_from, float* a_to) {
+  if (!c->sched_set) return fail(c, PNPI_ESTATE, "pnpi_set_scheduler not called");
+  const int n = c->cfg.n_train_timesteps;
+  if (t < 0 || t >= n) return fail(c, PNPI_EINVAL, "timestep out of range");
+  if (forward) {  // next_step: (min(t - ratio, 999)) -> t
+    int tp = t - ratio; if (tp > n - 1) tp = n - 1;
+    *a_from = tp >= 0 ? c->ac[tp] : c->final_alpha;
+    *a_to = c->ac[t];
+  } else {        // prev_step: t -> t - ratio
+    int tp = t - ratio;
+    *a_from = c->ac[t];
+    *a_to = tp >= 0 ? c->ac[tp] : c->final_alpha;
+  }
+  return 0;
+}
+
+int pnpi_ddim_next_step(pnpi_ctx* c, const float* eps, int t, int ratio, const float* sample, size_t n, float* out) {
+  float af, at; CKP(alphas_for(c, t, ratio, true, &af, &at));
+  CK(launch_ddim_move(sample, eps, af, at, n, out, c->st));
+  return 0;
+}
+int pnpi_ddim_prev_step(pnpi_ctx* c, const float* eps, int t, int ratio, const float* sample, size_t n, float* out) {
+  float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+  CK(launch_ddim_move(sample, eps, af, at, n, out, c->st));
+  return 0;
+}
+int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, int rpi, size_t row_elems, float gs, int t, int ratio,
+                       const float* noise_loss, int offset_rows, const float* target, float* offset_out, float* x_out) {
+  float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+  CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_out, x_out, c->st));
+  return 0;
+}
+
+// ---- level 2 loops. Scratch for the loops lives at the top of the controller arena (after the controller tables).
+int pnpi_ddim_invert(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_cond, int nsteps, const int* ts, float* all) {
+  if (!c || !z0 || !ctx_cond || !ts || !all || nsteps <= 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
+  const int ratio = g.n_train_timesteps / nsteps;
+  CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  float* eps = misc_f(c, (size_t)nimg * E);
+  CKH(hipMemcpyAsync(all, z0, (size_t)nimg * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[nsteps - i - 1];
+    const float* cur = all + (size_t)i * nimg * E;
+    int r = unet_fwd(c, cur, nimg, t, ctx_cond, false, 0, eps);
+    if (r) return r;
+    float af, at; CKP(alphas_for(c, t, ratio, true, &af, &at));
+    CK(launch_ddim_move(cur, eps, af, at, (size_t)nimg * E, all + (size_t)(i + 1) * nimg * E, c->st));
+  }
+  return 0;
+}
+
+static int upload_ints(pnpi_ctx* c, const std::vector<int>& v, int** dst) {
+  *dst = (int*)c->ctrl_arena.alloc(v.size() * sizeof(int));
+  return upload(c, *dst, v.data(), v.size() * sizeof(int));
+}
+
+int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, int nsteps, const int* ts, float gs,
+                          float* noise_loss_out) {
+  if (!c || !lat_all || !context4 || !ts || !noise_loss_out || nsteps <= 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
+  const int ratio = g.n_train_timesteps / nsteps, rows = 4 * nimg;
+  if (rows > c->max_rows) return fail(c, PNPI_EINVAL, "nimg * 4 exceeds max_unet_rows");
+  CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  float* cur = misc_f(c, (size_t)nimg * 2 * E);
+  float* in = misc_f(c, (size_t)rows * E);
+  float* eps = misc_f(c, (size_t)rows * E);
+  std::vector<int> expand(nimg * 2), inmap(rows);
+  for (int i = 0; i < nimg; ++i) { expand[2 * i] = i; expand[2 * i + 1] = i; for (int k = 0; k < 4; ++k) inmap[4 * i + k] = 2 * i + (k & 1); }
+  int *d_expand, *d_inmap;
+  CKP(upload_ints(c, expand, &d_expand));
+  CKP(upload_ints(c, inmap, &d_inmap));
+  CK(launch_gather_rows_f32(lat_all + (size_t)nsteps * nimg * E, d_expand, nimg * 2, E, cur, c->st));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[i];
+    CK(launch_gather_rows_f32(cur, d_inmap, rows, E, in, c->st));
+    int r = unet_fwd(c, in, rows, t, context4, false, 0, eps);
+    if (r) return r;
+    float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+    const float* target = lat_all + (size_t)(nsteps - i - 1) * nimg * E;
+    CK(launch_cfg_ddim_prev(eps, cur, nimg, 2, E, gs, af, at, nullptr, 0, target, noise_loss_out + (size_t)i * nimg * 2 * E, cur, c->st));
+  }
+  return 0;
+}
+
+int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
+                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, float* latents_out) {
+  if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
+  const int ratio = g.n_train_timesteps / nsteps, rows = 4 * nimg;
+  if (rows > c->max_rows) return fail(c, PNPI_EINVAL, "nimg * 4 exceeds max_unet_rows");
+  if (ctrl_host) CKP(setup_ctrl(c, ctrl_host, nimg, rows));
+  else CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  const bool use_ctrl = ctrl_host != nullptr;
+  float* lat = misc_f(c, (size_t)nimg * 2 * E);
+  float* in = misc_f(c, (size_t)rows * E);
+  float* eps = misc_f(c, (size_t)rows * E);
+  std::vector<int> expand(nimg * 2), inmap(rows);
+  for (int i = 0; i < nimg; ++i) { expand[2 * i] = i; expand[2 * i + 1] = i; for (int k = 0; k < 4; ++k) inmap[4 * i + k] = 2 * i + (k & 1); }
+  int *d_expand, *d_inmap;
+  CKP(upload_ints(c, expand, &d_expand));
+  CKP(upload_ints(c, inmap, &d_inmap));
+  CK(launch_gather_rows_f32(x_T, d_expand, nimg * 2, E, lat, c->st));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[i];
+    CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
+    int r = unet_fwd(c, in, rows, t, context4, use_ctrl, i, eps);
+    if (r) return r;
+    float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+    const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
+    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, nullptr, lat, c->st));
+    if (use_ctrl) CKP(apply_local_blend(c, lat, i));
+  }
+  CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- kernel-level ops
+int pnpi_op_conv(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int H, int W, int ksize, int stride, int pad,
+                 int ups, int Ho, int Wo, const void* w, const float* bias, const void* res, int N, void* out, int force_cfg,
+                 int force_split) {
+  GemmP p; gemm_defaults(p);
+  p.x1 = (const half_t*)x1; p.x2 = (const half_t*)x2; p.C1 = C1; p.C2 = C2; p.ldx1 = C1; p.ldx2 = C2;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups;
+  p.K = ksize * ksize * (C1 + C2); p.w = (const half_t*)w; p.ldw = p.K; p.M = B * Ho * Wo; p.N = N;
+  p.bias = bias; p.res = (const half_t*)res; p.ldres = N; p.out = (half_t*)out; p.ldo = N;
+  CK(launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, force_cfg, force_split));
+  return 0;
+}
+int pnpi_op_gemm(pnpi_ctx* c, const void* a, int lda, const void* w, int ldw, int M, int N, int K, float alpha, const float* bias,
+                 const void* res, void* out, int ldo, int vt_col0, void* outT, int vt_ld, int vt_f32, int rpb, int force_cfg,
+                 int force_split) {
+  GemmP p; gemm_defaults(p);
+  p.x1 = (const half_t*)a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
+  p.w = (const half_t*)w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.bias = bias; p.res = (const half_t*)res;
+  p.ldres = N; p.out = (half_t*)out; p.ldo = ldo;
+  if (outT) { p.outT = outT; p.vt_col0 = vt_col0; p.vt_ld = vt_ld; p.vt_f32 = vt_f32; p.rows_per_batch = rpb; }
+  CK(launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, force_cfg, force_split));
+  return 0;
+}
+int pnpi_op_groupnorm(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                      const float* beta, int silu, void* out) {
+  CK(launch_groupnorm((const half_t*)x1, (const half_t*)x2, C1, C2, B, HW, G, eps, gamma, beta, silu, (half_t*)out, c->gn_partial, c->st));
+  return 0;
+}
+int pnpi_op_layernorm(pnpi_ctx* c, const void* x, int M, int C, float eps, const float* gamma, const float* beta, void* out) {
+  CK(launch_layernorm((const half_t*)x, M, C, eps, gamma, beta, (half_t*)out, c->st));
+  return 0;
+}
+int pnpi_op_geglu(pnpi_ctx* c, const void* x, int M, int inner, void* out) {
+  CK(launch_geglu((const half_t*)x, M, inner, (half_t*)out, c->st));
+  return 0;
+}
+int pnpi_op_softmax_rows(pnpi_ctx* c, void* x, int M, int N, int ld) {
+  CK(launch_softmax_rows((half_t*)x, M, N, ld, c->st));
+  return 0;
+}
+int pnpi_op_attention(pnpi_ctx* c, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt, int ldv,
+                      void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, const int* rows_dev, int nrows) {
+  AttnP a; a.q = (const half_t*)q; a.ldq = ldq; a.q_off = q_off; a.k = (const half_t*)k; a.ldk = ldk; a.k_off = k_off;
+  a.vt = (const half_t*)vt; a.ldv = ldv; a.o = (half_t*)o; a.ldo = ldo; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.Dp = Dp; a.dh = dh;
+  a.scale = scale; a.rows = rows_dev; a.nrows = nrows;
+  CK(launch_attn_flash(a, c->st));
+  return 0;
+}
+int pnpi_op_cross_edit(pnpi_ctx* c, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt, int ldv,
+                       void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, const int* pairs_dev, int npairs,
+                       const void* mmatT, const float* c1, const float* c2, const float* lb_alpha, float* lb_acc, int lb_slot0,
+                       int lb_nslots) {
+  CrossEditP e; e.q = (const half_t*)q; e.ldq = ldq; e.q_off = q_off; e.k = (const half_t*)k; e.ldk = ldk; e.k_off = k_off;
+  e.vt = (const half_t*)vt; e.ldv = ldv; e.o = (half_t*)o; e.ldo = ldo; e.heads = heads; e.Nq = Nq; e.Nk = Nk; e.Dp = Dp; e.dh = dh;
+  e.scale = scale; e.pairs = pairs_dev; e.npairs = npairs; e.mmatT = (const half_t*)mmatT; e.c1 = c1; e.c2 = c2;
+  e.lb_alpha = lb_alpha; e.lb_acc = lb_acc; e.lb_slot0 = lb_slot0; e.lb_nslots = lb_nslots;
+  CK(launch_attn_cross_edit(e, c->st));
+  return 0;
+}
+int pnpi_op_local_blend(pnpi_ctx* c, const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents, int nimg) {
+  CK(launch_local_blend(lb_acc, nslots, map_hw, lat_hw, C, th, latents, nimg, c->st));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,399 @@
+// Attention on MFMA for the SD-1.x head sizes (40/80/160 padded to 64/96/160), with the Prompt-to-Prompt controller fused in.
+//
+// Reference: the hooked CrossAttention forward, models/p2p/attention_control.py:20-47
+//   (sim = q k^T * scale -> softmax -> controller(attn) -> attn v), and the controllers
+//   AttentionControl.__call__ :178-190, AttentionControlEdit.forward :269-282, AttentionReplace/Refine/Reweight :301-363,
+//   LocalBlend map accumulation via AttentionStore :221-234.
+//
+// Dataflow (per wavefront = 32 query rows, swapped-operand form):
+//   S^T = K Q^T   : MFMA A-operand = K tile rows (keys), B-operand = Q rows  -> lane l owns query (l & 31) and 16 of the
+//                   32 keys of a tile in its accumulator registers (the other 16 live in lane l ^ 32).
+//   softmax       : in registers, one __shfl_xor(.,32) per reduction; running max / sum (flash style) for self-attention.
+//   O^T = V^T P^T : A-operand = V^T rows (head-dim), B-operand = P straight from the accumulator registers (the MFMA k-slot
+//                   permutation is applied to the V^T fragment instead, two ds_read_b64 per fragment), so P never touches LDS.
+// Score matrices are never materialised (the reference materialises [B*8, N, N] fp32: 2.1 GB at 64x64).
+// Self-attention replacement ("tgt probabilities := src probabilities", attention_control.py:258-263) costs nothing here:
+// the target row simply takes Q and K from the source row (rows[] indirection) and keeps its own V.
+#include "ops.h"
+
+static constexpr int KV_TILE = 64;
+static constexpr int SV_LD = KV_TILE + 4;  // halfs; 136-byte rows: conflict-free ds_read_b64 over 32 rows
+
+template <int DP>
+__global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
+  constexpr int KS = DP / 16;  // k-steps over the head dim for S
+  constexpr int OT = DP / 32;  // 32-wide output tiles over the head dim
+  constexpr int SK_LD = DP + 8;
+  __shared__ __attribute__((aligned(16))) half_t sK[KV_TILE * SK_LD];
+  __shared__ __attribute__((aligned(16))) half_t sV[DP * SV_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  const int head = blockIdx.y;
+  const int* rw = p.rows + blockIdx.z * 4;
+  const int orow = rw[0], qrow = rw[1], krow = rw[2], vrow = rw[3];
+  const int qtok = blockIdx.x * 128 + wave * 32 + ql;
+  const bool qok = qtok < p.Nq;
+
+  half8 qf[KS];
+  {
+    const half_t* qp = p.q + ((size_t)qrow * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
+  }
+  floatx16 O[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[ot][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;
+
+  const half_t* kbase = p.k + (size_t)krow * p.Nk * p.ldk + p.k_off + head * DP;
+  const half_t* vbase = p.vt + ((size_t)vrow * p.heads + head) * DP * (size_t)p.ldv;
+
+  for (int kv0 = 0; kv0 < p.Nk; kv0 += KV_TILE) {
+    __syncthreads();
+    for (int idx = tid; idx < KV_TILE * (DP / 8); idx += 256) {
+      int r = idx / (DP / 8), v = idx - r * (DP / 8);
+      int tok = kv0 + r;
+      half8 val = tok < p.Nk ? ldg_half8(kbase + (size_t)tok * p.ldk + v * 8) : zero_half8();
+      *reinterpret_cast<half8*>(sK + r * SK_LD + v * 8) = val;
+    }
+    for (int idx = tid; idx < DP * (KV_TILE / 8); idx += 256) {
+      int d = idx >> 3, v = idx & 7;
+      int tok0 = kv0 + v * 8;
+      const half_t* src = vbase + (size_t)d * p.ldv + tok0;
+      half8 val;
+      if (tok0 + 8 <= p.Nk) {
+        val = ldg_half8(src);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val[j] = (tok0 + j < p.Nk) ? src[j] : (half_t)0.f;
+      }
+      half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
+      *reinterpret_cast<half4*>(sV + d * SV_LD + v * 8) = lo;
+      *reinterpret_cast<half4*>(sV + d * SV_LD + v * 8 + 4) = hi;
+    }
+    __syncthreads();
+
+    floatx16 s[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half8 kf = *reinterpret_cast<const half8*>(sK + (st * 32 + ql) * SK_LD + ks * 16 + h * 8);
+        s[st] = mfma32(kf, qf[ks], s[st]);
+      }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int key = kv0 + st * 32 + acc_row(r, lane);
+        float v = key < p.Nk ? s[st][r] : -INFINITY;
+        s[st][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(mrun, mloc);
+    const float alpha = exp2f((mrun - mnew) * c);
+    float psum = 0.f;
+    half8 pf[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = exp2f((s[st][r] - mnew) * c);
+        psum += pv;
+        pf[st][r >> 3][r & 7] = (half_t)pv;
+      }
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[ot][r] *= alpha;
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half_t* vb = sV + (ot * 32 + ql) * SV_LD + st * 32 + t * 16 + 4 * h;
+          half4 lo = *reinterpret_cast<const half4*>(vb);
+          half4 hi = *reinterpret_cast<const half4*>(vb + 8);
+          half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          O[ot] = mfma32(vf, pf[st][t], O[ot]);
+        }
+    }
+  }
+  const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+  const float inv = 1.f / ltot;
+  if (qok) {
+    half_t* op = p.o + ((size_t)orow * p.Nq + qtok) * p.ldo + head * p.dh;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int d = ot * 32 + 8 * g + 4 * h;
+        if (d + 3 < p.dh) {
+          half4 o4 = {(half_t)(O[ot][4 * g] * inv), (half_t)(O[ot][4 * g + 1] * inv), (half_t)(O[ot][4 * g + 2] * inv),
+                      (half_t)(O[ot][4 * g + 3] * inv)};
+          *reinterpret_cast<half4*>(op + d) = o4;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (d + j < p.dh) op[d + j] = (half_t)(O[ot][4 * g + j] * inv);
+        }
+      }
+  }
+}
+
+int launch_attn_flash(const AttnP& p, hipStream_t st) {
+  if (p.nrows <= 0) return 0;
+  if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.q_off & 7) || (p.k_off & 7) || (p.dh & 3) || (p.ldo & 3)) return -3;
+  dim3 grid((p.Nq + 127) / 128, p.heads, p.nrows);
+  switch (p.Dp) {
+    case 32: attn_flash_kernel<32><<<grid, 256, 0, st>>>(p); break;
+    case 64: attn_flash_kernel<64><<<grid, 256, 0, st>>>(p); break;
+    case 96: attn_flash_kernel<96><<<grid, 256, 0, st>>>(p); break;
+    case 128: attn_flash_kernel<128><<<grid, 256, 0, st>>>(p); break;
+    case 160: attn_flash_kernel<160><<<grid, 256, 0, st>>>(p); break;
+    default: return -5;
+  }
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cross-attention (<= 96 text tokens) for one (source, target) conditional row pair with the P2P edit fused in:
+//   P_src = softmax(Q_src K_src^T), P_tgt = softmax(Q_tgt K_tgt^T)
+//   P_tgt' = c1[j] * (P_src . Mmat)[j] + c2[j] * P_tgt[j]          (no renormalisation, as in the reference)
+//   O_src = P_src V_src ; O_tgt = P_tgt' V_tgt
+//   LocalBlend accumulators += sum_j lb_alpha[i][j] * P_i[q][j]    (i = src: unedited map, i = tgt: post-edit map)
+// c1/c2 encode AttentionReplace / AttentionRefine (+ AttentionReweight) and the cross_replace_alpha schedule:
+//   c1 = a_t * eq * alphas ; c2 = a_t * eq * (1 - alphas) + (1 - a_t)       (attention_control.py:276-277,303-304,319-323,340-345)
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr int CE_KEYS = 96;
+static constexpr int CE_LD = CE_KEYS + 4;  // halfs per row of the V^T / Mmat^T tiles (200 B, 8-byte aligned)
+
+template <int DP>
+__global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
+  constexpr int KS = DP / 16, OT = DP / 32, SK_LD = DP + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  half_t* sK = reinterpret_cast<half_t*>(smem_raw);   // [2][96][SK_LD]   (src, tgt)
+  half_t* sV = sK + 2 * CE_KEYS * SK_LD;              // [2][DP][CE_LD]
+  half_t* sM = sV + 2 * DP * CE_LD;                   // [96][CE_LD]      Mmat^T[j][w]
+  float* sC = reinterpret_cast<float*>(sM + CE_KEYS * CE_LD);  // c1[96], c2[96], lb_alpha[2][96]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  const int head = blockIdx.y, pair = blockIdx.z;
+  const int rows2[2] = {p.pairs[pair * 2 + 0], p.pairs[pair * 2 + 1]};
+  const int qtok = blockIdx.x * 128 + wave * 32 + ql;
+  const bool qok = qtok < p.Nq;
+
+  // ---- stage K, V^T (both rows), Mmat^T and the coefficient vectors
+  for (int which = 0; which < 2; ++which) {
+    const int row = rows2[which];
+    const half_t* kbase = p.k + (size_t)row * p.Nk * p.ldk + p.k_off + head * DP;
+    for (int idx = tid; idx < CE_KEYS * (DP / 8); idx += 256) {
+      int r = idx / (DP / 8), v = idx - r * (DP / 8);
+      half8 val = r < p.Nk ? ldg_half8(kbase + (size_t)r * p.ldk + v * 8) : zero_half8();
+      *reinterpret_cast<half8*>(sK + (which * CE_KEYS + r) * SK_LD + v * 8) = val;
+    }
+    const half_t* vbase = p.vt + ((size_t)row * p.heads + head) * DP * (size_t)p.ldv;
+    for (int idx = tid; idx < DP * (CE_KEYS / 4); idx += 256) {
+      int d = idx / (CE_KEYS / 4), v = idx - d * (CE_KEYS / 4);
+      half4 val;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { int tok = v * 4 + j; val[j] = tok < p.Nk ? vbase[(size_t)d * p.ldv + tok] : (half_t)0.f; }
+      *reinterpret_cast<half4*>(sV + (which * DP + d) * CE_LD + v * 4) = val;
+    }
+  }
+  {
+    const half_t* mm = p.mmatT + (size_t)pair * CE_KEYS * CE_KEYS;
+    for (int idx = tid; idx < CE_KEYS * (CE_KEYS / 4); idx += 256) {
+      int j = idx / (CE_KEYS / 4), v = idx - j * (CE_KEYS / 4);
+      half4 val = *reinterpret_cast<const half4*>(mm + j * CE_KEYS + v * 4);
+      *reinterpret_cast<half4*>(sM + j * CE_LD + v * 4) = val;
+    }
+    for (int idx = tid; idx < CE_KEYS; idx += 256) {
+      sC[idx] = p.c1[pair * CE_KEYS + idx];
+      sC[CE_KEYS + idx] = p.c2[pair * CE_KEYS + idx];
+      sC[2 * CE_KEYS + idx] = p.lb_alpha ? p.lb_alpha[(pair * 2 + 0) * CE_KEYS + idx] : 0.f;
+      sC[3 * CE_KEYS + idx] = p.lb_alpha ? p.lb_alpha[(pair * 2 + 1) * CE_KEYS + idx] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const float c = p.scale * 1.44269504088896340736f;
+  floatx16 P[2][3];  // normalised probabilities, [src/tgt][key tile]
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    half8 qf[KS];
+    const half_t* qp = p.q + ((size_t)rows2[which] * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
+    float mx = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      floatx16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half8 kf = *reinterpret_cast<const half8*>(sK + (which * CE_KEYS + st * 32 + ql) * SK_LD + ks * 16 + h * 8);
+        s = mfma32(kf, qf[ks], s);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int key = st * 32 + acc_row(r, lane);
+        float v = key < p.Nk ? s[r] : -INFINITY;
+        s[r] = v;
+        mx = fmaxf(mx, v);
+      }
+      P[which][st] = s;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = exp2f((P[which][st][r] - mx) * c);
+        P[which][st][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P[which][st][r] *= inv;
+  }
+
+  // fp16 MFMA B-operand fragments of P_src (k-slot order = accumulator register order)
+  half8 pfs[3][2];
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pfs[st][r >> 3][r & 7] = (half_t)P[0][st][r];
+
+  // mapped^T[j][q] = sum_w Mmat^T[j][w] * P_src^T[w][q]; then the blend, written over P_tgt
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+    floatx16 mp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mp[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const half_t* mb = sM + (jt * 32 + ql) * CE_LD + st * 32 + t * 16 + 4 * h;
+        half4 lo = *reinterpret_cast<const half4*>(mb);
+        half4 hi = *reinterpret_cast<const half4*>(mb + 8);
+        half8 mf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        mp = mfma32(mf, pfs[st][t], mp);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int j = jt * 32 + acc_row(r, lane);
+      P[1][jt][r] = sC[j] * mp[r] + sC[CE_KEYS + j] * P[1][jt][r];
+    }
+  }
+
+  // LocalBlend accumulators (deterministic: each (slot, branch, query) word has exactly one writer per launch)
+  if (p.lb_acc) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      float acc = 0.f;
+#pragma unroll
+      for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int j = st * 32 + acc_row(r, lane);
+          acc += sC[(2 + which) * CE_KEYS + j] * P[which][st][r];
+        }
+      acc += __shfl_xor(acc, 32, 64);
+      if (h == 0 && qok) {
+        float* dst = p.lb_acc + (((size_t)pair * p.lb_nslots + p.lb_slot0 + head) * 2 + which) * p.Nq + qtok;
+        *dst += acc;
+      }
+    }
+  }
+
+  // O = P V for both rows
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    half8 pf[3][2];
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pf[st][r >> 3][r & 7] = (half_t)P[which][st][r];
+    half_t* op = p.o + ((size_t)rows2[which] * p.Nq + (qok ? qtok : 0)) * p.ldo + head * p.dh;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      floatx16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half_t* vb = sV + (which * DP + ot * 32 + ql) * CE_LD + st * 32 + t * 16 + 4 * h;
+          half4 lo = *reinterpret_cast<const half4*>(vb);
+          half4 hi = *reinterpret_cast<const half4*>(vb + 8);
+          half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o = mfma32(vf, pf[st][t], o);
+        }
+      if (qok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int d = ot * 32 + 8 * g + 4 * h;
+          if (d + 3 < p.dh) {
+            half4 o4 = {(half_t)o[4 * g], (half_t)o[4 * g + 1], (half_t)o[4 * g + 2], (half_t)o[4 * g + 3]};
+            *reinterpret_cast<half4*>(op + d) = o4;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (d + j < p.dh) op[d + j] = (half_t)o[4 * g + j];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int DP>
+static size_t ce_lds_bytes() {
+  return (size_t)(2 * CE_KEYS * (DP + 8) + 2 * DP * CE_LD + CE_KEYS * CE_LD) * sizeof(half_t) + 4 * CE_KEYS * sizeof(float);
+}
+
+template <int DP>
+static int launch_ce(const CrossEditP& p, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t lds = ce_lds_bytes<DP>();
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_cross_edit_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((p.Nq + 127) / 128, p.heads, p.npairs);
+  attn_cross_edit_kernel<DP><<<grid, 256, lds, st>>>(p);
+  return (int)hipGetLastError();
+}
+
+int launch_attn_cross_edit(const CrossEditP& p, hipStream_t st) {
+  if (p.npairs <= 0) return 0;
+  if (p.Nk > CE_KEYS) return -6;
+  if ((p.ldq & 7) || (p.ldk & 7) || (p.q_off & 7) || (p.k_off & 7) || (p.dh & 3) || (p.ldo & 3)) return -3;
+  switch (p.Dp) {
+    case 32: return launch_ce<32>(p, st);
+    case 64: return launch_ce<64>(p, st);
+    case 96: return launch_ce<96>(p, st);
+    case 128: return launch_ce<128>(p, st);
+    case 160: return launch_ce<160>(p, st);
+    default: return -5;
+  }
+}

@@ -1,0 +1,56 @@
+// Shared device/host definitions for the pnpi gfx950 kernels.
+// CDNA4 only: 64-lane wavefronts, v_mfma_f32_32x32x16_f16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define PNPI_WAVE 64
+
+// D = A(32 x 16) * B(16 x 32) + C, f16 inputs, f32 accumulate.
+//   A operand: lane l holds row (l & 31), k-slots (l >> 5) * 8 + [0, 8)
+//   B operand: lane l holds col (l & 31), k-slots (l >> 5) * 8 + [0, 8)
+//   C/D      : lane l holds col (l & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r in [0, 16)
+// The hardware contracts over matching (lane >> 5, slot) pairs, so any k permutation that is applied
+// identically to both operands is legal; the attention kernels rely on that.
+__device__ __forceinline__ floatx16 mfma32(half8 a, half8 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ half8 zero_half8() {
+  half8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (half_t)0.f;
+  return z;
+}
+
+__device__ __forceinline__ half8 ldg_half8(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+#define HIP_CHECK_RET(expr)                         \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return (int)_e;           \
+  } while (0)

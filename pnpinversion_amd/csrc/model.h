@@ -1,0 +1,158 @@
+// Host-side model description for libpnpi: weight slots, SD-1.x UNet / VAE graphs, workspace planning.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pnpi.h"
+#include "ops.h"
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int round_up_i(int x, int a) { return (x + a - 1) / a * a; }
+
+// Bump allocator. With base == nullptr it only measures (dry run) and hands out fake, never-dereferenced addresses.
+struct Bump {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool overflow = false;
+  void* alloc(size_t bytes) {
+    off = align_up(off, 256);
+    size_t at = off;
+    off += bytes;
+    if (off > peak) peak = off;
+    if (base && off > cap) { overflow = true; return base; }
+    return base ? (void*)(base + at) : (void*)(uintptr_t)(0x1000 + at);
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+  void reset() { off = 0; }
+};
+
+struct Slot {
+  int kind;      // 0 = matrix (fp16), 1 = vector (fp32)
+  void* dst;
+  int rows, cols, taps, dst_ld, cin_pad, row0, dh, Dp;
+  int n;
+  bool loaded;
+};
+
+struct ConvW { half_t* w; float* b; int cin, cin_pad, cout, k; };
+struct LinW { half_t* w; float* b; int in, out; };
+struct NormW { float* g; float* b; int c; };
+
+struct ResnetW {
+  NormW n1, n2;
+  ConvW c1, c2, sc;
+  bool has_sc;
+  int temb_off;   // >= 0: conv1 bias comes from the per-step bias_eff table at this offset; -1: static conv1 bias
+  int cin, cout;
+};
+
+struct TransformerW {
+  int C, heads, dh, Dp;
+  NormW gn, ln1, ln2, ln3;
+  ConvW proj_in, proj_out;
+  half_t* w_qkv;      // [3*heads*Dp][C]   (self-attention, heads zero-padded to Dp)
+  LinW o1;            // [C][C] + bias
+  half_t* w_q2;       // [heads*Dp][C]
+  half_t* w_kv2;      // [2*heads*Dp][cross_dim]
+  LinW o2;
+  LinW ff1;           // [8C][C]
+  LinW ff2;           // [C][4C]
+  int place;          // 0 down, 1 mid, 2 up
+  int lb_slot0;       // first LocalBlend slot of this layer's cross-attention, or -1
+};
+
+struct VaeAttnW {
+  int C;
+  NormW gn;
+  half_t* w_qkv; float* b_qkv;   // [3C][C]
+  LinW proj;
+};
+
+struct UNetW {
+  ConvW conv_in, conv_out;
+  NormW norm_out;
+  LinW t1, t2;
+  half_t* temb_w;     // [sumC][4*C0]
+  float* temb_b;      // [sumC] time_emb_proj biases
+  float* conv1_b;     // [sumC] conv1 biases
+  int temb_total;
+  std::vector<std::vector<ResnetW>> down_res;
+  std::vector<std::vector<TransformerW>> down_attn;
+  std::vector<ConvW> down_samp;     // size n_blocks-1
+  ResnetW mid_res[2];
+  TransformerW mid_attn;
+  std::vector<std::vector<ResnetW>> up_res;
+  std::vector<std::vector<TransformerW>> up_attn;
+  std::vector<ConvW> up_samp;
+  int lb_nslots, lb_tokens;         // LocalBlend slots (5 layers x heads) and their token count (256), 0 if unavailable
+};
+
+struct VaeW {
+  // encoder
+  ConvW e_conv_in, e_conv_out;
+  std::vector<std::vector<ResnetW>> e_res;
+  std::vector<ConvW> e_down;
+  ResnetW e_mid[2];
+  VaeAttnW e_attn;
+  NormW e_norm_out;
+  ConvW quant;       // 1x1, 2L -> 2L
+  // decoder
+  ConvW post_quant;  // 1x1, L -> L (stored as 8 -> 8, zero padded)
+  ConvW d_conv_in, d_conv_out;
+  ResnetW d_mid[2];
+  VaeAttnW d_attn;
+  std::vector<std::vector<ResnetW>> d_res;
+  std::vector<ConvW> d_up;
+  NormW d_norm_out;
+};
+
+struct Tensor4 { half_t* p; int B, H, W, C; };
+
+struct CtrlDev {
+  bool any_edit = false;
+  int nimg = 0, n_alpha_rows = 0;
+  int npairs = 0;                 // images with kind == 1
+  int lb_any = 0;
+  std::vector<int> lb_start;      // per pair
+  std::vector<float> lb_th;
+  std::vector<int> lb_enabled;
+  std::vector<int> pair_img;      // pair -> image
+  int self_lo = 0, self_hi = 0, self_max_tokens = 0;
+  // device tables
+  int* rows_id = nullptr;         // [rows][4] identity
+  int* rows_rep = nullptr;        // [rows][4] self-attention replacement
+  int* rows_plain = nullptr;      // rows that take the plain cross-attention path
+  int n_plain = 0;
+  int* pairs = nullptr;           // [npairs][2]
+  half_t* mmatT = nullptr;        // [npairs][96][96]
+  float* coef = nullptr;          // [n_alpha_rows][2][npairs][96]  (c1 block, c2 block per step)
+  float* lb_alpha = nullptr;      // [npairs][2][96]
+  float* lb_acc = nullptr;        // [npairs][nslots][2][tokens]
+};
+
+struct pnpi_ctx {
+  pnpi_model_config cfg;
+  int device;
+  hipStream_t st;
+  std::string err;
+  int max_rows, max_vae;
+  bool dry;
+  Bump warena, persist, temp, ctrl_arena;
+  float* splitk_ws; size_t splitk_bytes;
+  float* gn_partial;
+  float* temb_table;      // [n_train][C0] fp32 sinusoid table
+  float* temb_h;          // [4*C0]
+  float* temb_emb;        // [4*C0]
+  float* bias_eff;        // [temb_total]
+  std::unordered_map<std::string, Slot> slots;
+  UNetW unet;
+  VaeW vae;
+  std::vector<float> ac;
+  float final_alpha;
+  bool sched_set;
+  pnpi_counters ctr;
+  CtrlDev cd;
+  std::vector<char> host_stage;
+};

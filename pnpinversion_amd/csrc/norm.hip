@@ -1,0 +1,410 @@
+// Bandwidth-bound kernels: GroupNorm(+SiLU), LayerNorm, GEGLU, row softmax, GEMV, layout/dtype conversions.
+// Reference ops restated: torch.nn.GroupNorm (my_diffusers/models/resnet.py:287,296; attention.py:123; unet_2d_condition.py:163),
+// torch.nn.LayerNorm (attention.py:186-188), GEGLU (attention.py:323-333), softmax (attention.py:77),
+// TimestepEmbedding / time_emb_proj linears (embeddings.py:63-80, resnet.py:292,349).
+// All statistics are fp32; 16-byte (8 x fp16) vector accesses, NHWC so that a wavefront reads contiguous channels.
+#include "ops.h"
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// Pass 1: per (batch, pixel-chunk) partial sums per group. Each thread owns a fixed 8-channel vector and walks pixels;
+// the per-channel sums are reduced in a fixed order (deterministic, no atomics).
+__global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1,
+                                                       int C2, int HW, int G, int nchunk, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_part = reinterpret_cast<float*>(smem_raw);  // [TP][C][2]
+  const int C = C1 + C2, C8 = C >> 3;
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int TC = C8 < 256 ? C8 : 256;
+  const int TP = 256 / TC;
+  const int tc = threadIdx.x % TC, tp = threadIdx.x / TC;
+  const int ppc = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  if (tp < TP) {
+    for (int cv = tc; cv < C8; cv += TC) {
+      float s[8], q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+      const int c = cv * 8;
+      const half_t* src; int ld, cc;
+      if (c < C1) { src = x1; ld = C1; cc = c; } else { src = x2; ld = C2; cc = c - C1; }
+      for (int pix = p0 + tp; pix < p1; pix += TP) {
+        half8 v = ldg_half8(src + ((size_t)b * HW + pix) * ld + cc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s_part[((size_t)tp * C + c + j) * 2 + 0] = s[j];
+        s_part[((size_t)tp * C + c + j) * 2 + 1] = q[j];
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < TP; ++t)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        s += s_part[((size_t)t * C + c) * 2 + 0];
+        q += s_part[((size_t)t * C + c) * 2 + 1];
+      }
+    float* dst = partial + (((size_t)b * nchunk + chunk) * G + g) * 2;
+    dst[0] = s;
+    dst[1] = q;
+  }
+}
+
+// Pass 2: finalize the statistics (fixed chunk order), fold gamma/beta into per-channel scale/shift, stream the pixels.
+__global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1,
+                                                       int C2, int HW, int G, int nchunk, int napply, float eps,
+                                                       const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int silu, half_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int C = C1 + C2, C8 = C >> 3;
+  float* s_scale = reinterpret_cast<float*>(smem_raw);  // [C]
+  float* s_shift = s_scale + C;                          // [C]
+  float* s_mean = s_shift + C;                           // [G]
+  float* s_rstd = s_mean + G;                            // [G]
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* src = partial + (((size_t)b * nchunk + ch) * G + g) * 2;
+      s += src[0];
+      q += src[1];
+    }
+    const float n = (float)HW * (float)cpg;
+    float mean = s / n;
+    float var = q / n - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    s_mean[g] = mean;
+    s_rstd[g] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    int g = c / cpg;
+    float sc = s_rstd[g] * gamma[c];
+    s_scale[c] = sc;
+    s_shift[c] = beta[c] - s_mean[g] * sc;
+  }
+  __syncthreads();
+  const int ppc = (HW + napply - 1) / napply;
+  const int p0 = blockIdx.y * ppc, p1 = min(HW, p0 + ppc);
+  const size_t nvec = (size_t)(p1 > p0 ? p1 - p0 : 0) * C8;
+  for (size_t idx = threadIdx.x; idx < nvec; idx += blockDim.x) {
+    int pix = p0 + (int)(idx / C8);
+    int c = (int)(idx % C8) * 8;
+    const half_t* src; int ld, cc;
+    if (c < C1) { src = x1; ld = C1; cc = c; } else { src = x2; ld = C2; cc = c - C1; }
+    half8 v = ldg_half8(src + ((size_t)b * HW + pix) * ld + cc);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * s_scale[c + j] + s_shift[c + j];
+      if (silu) f = silu_f(f);
+      o[j] = (half_t)f;
+    }
+    *reinterpret_cast<half8*>(out + ((size_t)b * HW + pix) * C + c) = o;
+  }
+}
+
+static int gn_nchunk(int HW) { int n = HW / 64; if (n < 1) n = 1; if (n > 128) n = 128; return n; }
+static int gn_napply(int HW) { int n = HW / 16; if (n < 1) n = 1; if (n > 1024) n = 1024; return n; }
+
+int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                     const float* beta, int silu, half_t* out, float* partial, hipStream_t st) {
+  const int C = C1 + C2;
+  if ((C & 7) || (C1 & 7) || C % G) return -3;
+  const int C8 = C >> 3;
+  const int TC = C8 < 256 ? C8 : 256, TP = 256 / TC;
+  const int nchunk = gn_nchunk(HW);
+  size_t lds1 = (size_t)TP * C * 2 * sizeof(float);
+  gn_stats_kernel<<<dim3(B, nchunk), 256, lds1, st>>>(x1, x2, C1, C2, HW, G, nchunk, partial);
+  size_t lds2 = (size_t)(2 * C + 2 * G) * sizeof(float);
+  const int napply = gn_napply(HW);
+  gn_apply_kernel<<<dim3(B, napply), 256, lds2, st>>>(x1, x2, C1, C2, HW, G, nchunk, napply, eps, partial, gamma, beta, silu, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wavefront per token row; the row stays in registers (C <= 2048) so mean and variance are two exact passes.
+__global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict__ x, int M, int C, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        half_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C8 = C >> 3;
+  half8 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int cv = lane + 64 * i;
+    if (cv < C8) {
+      v[i] = ldg_half8(x + (size_t)row * C + cv * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int cv = lane + 64 * i;
+    if (cv < C8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
+    }
+  }
+  q = wave_sum(q);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int cv = lane + 64 * i;
+    if (cv < C8) {
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int c = cv * 8 + j;
+        o[j] = (half_t)(((float)v[i][j] - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *reinterpret_cast<half8*>(out + (size_t)row * C + cv * 8) = o;
+    }
+  }
+}
+
+int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamma, const float* beta, half_t* out,
+                     hipStream_t st) {
+  if ((C & 7) || C > 2048) return -3;
+  layernorm_kernel<<<(M + 3) / 4, 256, 0, st>>>(x, M, C, eps, gamma, beta, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+__global__ void __launch_bounds__(256) geglu_kernel(const half_t* __restrict__ x, int M, int I, half_t* __restrict__ out) {
+  const int I8 = I >> 3;
+  const size_t total = (size_t)M * I8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t m = idx / I8;
+    int c = (int)(idx - m * I8) * 8;
+    half8 a = ldg_half8(x + m * 2 * I + c);
+    half8 g = ldg_half8(x + m * 2 * I + I + c);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] * gelu_f((float)g[j]));
+    *reinterpret_cast<half8*>(out + m * I + c) = o;
+  }
+}
+int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st) {
+  if (I & 7) return -3;
+  size_t total = (size_t)M * (I >> 3);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  geglu_kernel<<<blocks, 256, 0, st>>>(x, M, I, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ row softmax
+// One wavefront per row, in place (VAE AttentionBlock: 4096-wide rows; my_diffusers/models/attention.py:77).
+__global__ void __launch_bounds__(256) softmax_rows_kernel(half_t* __restrict__ x, int M, int N, int ld) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  half_t* p = x + (size_t)row * ld;
+  float mx = -INFINITY;
+  for (int c = lane * 8; c < N; c += 64 * 8) {
+    half8 v = ldg_half8(p + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[j]);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane * 8; c < N; c += 64 * 8) {
+    half8 v = ldg_half8(p + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += __expf((float)v[j] - mx);
+  }
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane * 8; c < N; c += 64 * 8) {
+    half8 v = ldg_half8(p + c);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(__expf((float)v[j] - mx) * inv);
+    *reinterpret_cast<half8*>(p + c) = o;
+  }
+}
+int launch_softmax_rows(half_t* x, int M, int N, int ld, hipStream_t st) {
+  if ((N & 7) || (ld & 7)) return -3;
+  softmax_rows_kernel<<<(M + 3) / 4, 256, 0, st>>>(x, M, N, ld);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ GEMV
+// out[n] = bias[n] + sum_k act(x[k]) * W[n][k]; one wavefront per output, fp32 accumulate (time-embedding MLP).
+__global__ void __launch_bounds__(256) gemv_kernel(const float* __restrict__ x, int K, const half_t* __restrict__ W, int N,
+                                                   const float* __restrict__ bias, const float* __restrict__ bias2, int silu_in,
+                                                   float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    half8 w = ldg_half8(W + (size_t)n * K + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xv = x[k + j];
+      if (silu_in) xv = silu_f(xv);
+      acc += xv * (float)w[j];
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[n] = acc + (bias ? bias[n] : 0.f) + (bias2 ? bias2[n] : 0.f);
+}
+int launch_gemv(const float* x, int K, const half_t* W, int N, const float* bias, const float* bias2, int silu_in, float* out,
+                hipStream_t st) {
+  if (K & 7) return -3;
+  gemv_kernel<<<(N + 3) / 4, 256, 0, st>>>(x, K, W, N, bias, bias2, silu_in, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ conversions
+__global__ void nchw_f32_to_nhwc_f16_kernel(const float* __restrict__ in, int B, int C, int HW, int Cp, half_t* __restrict__ out) {
+  const size_t total = (size_t)B * HW * Cp;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % Cp);
+    size_t bp = idx / Cp;
+    int pix = (int)(bp % HW);
+    int b = (int)(bp / HW);
+    out[idx] = c < C ? (half_t)in[((size_t)b * C + c) * HW + pix] : (half_t)0.f;
+  }
+}
+int launch_nchw_f32_to_nhwc_f16(const float* in, int B, int C, int HW, int Cp, half_t* out, hipStream_t st) {
+  size_t total = (size_t)B * HW * Cp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  nchw_f32_to_nhwc_f16_kernel<<<blocks, 256, 0, st>>>(in, B, C, HW, Cp, out);
+  return (int)hipGetLastError();
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, size_t n, half_t* __restrict__ out) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
+    out[idx] = (half_t)in[idx];
+}
+int launch_f32_to_f16(const float* in, size_t n, half_t* out, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  f32_to_f16_kernel<<<blocks, 256, 0, st>>>(in, n, out);
+  return (int)hipGetLastError();
+}
+
+// utils/utils.py:76-77: image.float() / 127.5 - 1, HWC u8 -> NHWC fp16 with the channel dim zero-padded to Cp.
+__global__ void img_u8_to_nhwc_kernel(const uint8_t* __restrict__ img, int n, int HW, int Cp, half_t* __restrict__ out) {
+  const size_t total = (size_t)n * HW * Cp;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % Cp);
+    size_t bp = idx / Cp;
+    float v = 0.f;
+    if (c < 3) v = __fsub_rn(__fdiv_rn((float)img[bp * 3 + c], 127.5f), 1.0f);
+    out[idx] = (half_t)v;
+  }
+}
+int launch_img_u8_to_nhwc(const uint8_t* img, int n, int HW, int Cp, half_t* out, hipStream_t st) {
+  size_t total = (size_t)n * HW * Cp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  img_u8_to_nhwc_kernel<<<blocks, 256, 0, st>>>(img, n, HW, Cp, out);
+  return (int)hipGetLastError();
+}
+
+// utils/utils.py:62-65: (x / 2 + 0.5).clamp(0, 1) * 255 -> uint8 (truncation), NCHW fp32 -> HWC u8.
+__global__ void dec_to_u8_kernel(const float* __restrict__ nchw, int n, int HW, uint8_t* __restrict__ out) {
+  const size_t total = (size_t)n * HW * 3;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % 3);
+    size_t bp = idx / 3;
+    int pix = (int)(bp % HW);
+    int b = (int)(bp / HW);
+    float v = nchw[((size_t)b * 3 + c) * HW + pix];
+    v = __fadd_rn(__fdiv_rn(v, 2.0f), 0.5f);
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    v = __fmul_rn(v, 255.0f);
+    out[idx] = (uint8_t)v;
+  }
+}
+int launch_dec_to_u8(const float* nchw, int n, int HW, uint8_t* out_hwc, hipStream_t st) {
+  size_t total = (size_t)n * HW * 3;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  dec_to_u8_kernel<<<blocks, 256, 0, st>>>(nchw, n, HW, out_hwc);
+  return (int)hipGetLastError();
+}
+
+__global__ void scale_f32_kernel(const float* __restrict__ in, size_t n, float s, float* __restrict__ out) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
+    out[idx] = __fmul_rn(in[idx], s);
+}
+int launch_scale_f32(const float* in, size_t n, float s, float* out, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  scale_f32_kernel<<<blocks, 256, 0, st>>>(in, n, s, out);
+  return (int)hipGetLastError();
+}
+
+__global__ void gather_rows_f32_kernel(const float* __restrict__ in, const int* __restrict__ rows, int nrows, size_t row_elems,
+                                       float* __restrict__ out) {
+  const size_t total = (size_t)nrows * row_elems;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx / row_elems, e = idx - r * row_elems;
+    out[idx] = in[(size_t)rows[r] * row_elems + e];
+  }
+}
+int launch_gather_rows_f32(const float* in, const int* rows, int nrows, size_t row_elems, float* out, hipStream_t st) {
+  size_t n = (size_t)nrows * row_elems;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  gather_rows_f32_kernel<<<blocks, 256, 0, st>>>(in, rows, nrows, row_elems, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ weight repack
+// src: PyTorch [rows][cols][taps] (conv [out][in][kh*kw] or linear [out][in], taps = 1)
+// dst: fp16 [row'][tap * cin_pad + c], row' = row0 + (dh ? (r / dh) * Dp + r % dh : r)   (attention heads padded to Dp)
+__global__ void repack_matrix_kernel(const void* __restrict__ src, int src_f16, int rows, int cols, int taps, half_t* __restrict__ dst,
+                                     int dst_ld, int cin_pad, int row0, int dh, int Dp) {
+  const size_t total = (size_t)rows * cols * taps;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int tap = (int)(idx % taps);
+    size_t rc = idx / taps;
+    int c = (int)(rc % cols);
+    int r = (int)(rc / cols);
+    float v = src_f16 ? (float)((const half_t*)src)[idx] : ((const float*)src)[idx];
+    int rr = row0 + (dh > 0 ? (r / dh) * Dp + (r % dh) : r);
+    dst[(size_t)rr * dst_ld + (size_t)tap * cin_pad + c] = (half_t)v;
+  }
+}
+int launch_repack_matrix(const void* src, int src_f16, int rows, int cols, int taps, half_t* dst, int dst_ld, int cin_pad, int row0,
+                         int dh, int Dp, hipStream_t st) {
+  size_t total = (size_t)rows * cols * taps;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  repack_matrix_kernel<<<blocks, 256, 0, st>>>(src, src_f16, rows, cols, taps, dst, dst_ld, cin_pad, row0, dh, Dp);
+  return (int)hipGetLastError();
+}
+__global__ void repack_vec_kernel(const void* __restrict__ src, int src_f16, int n, float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    dst[i] = src_f16 ? (float)((const half_t*)src)[i] : ((const float*)src)[i];
+}
+int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream_t st) {
+  int blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  repack_vec_kernel<<<blocks, 256, 0, st>>>(src, src_f16, n, dst);
+  return (int)hipGetLastError();
+}

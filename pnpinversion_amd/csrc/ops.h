@@ -1,0 +1,98 @@
+// Host-side launch wrappers for the gfx950 kernels (internal C++ interface; the public boundary is include/pnpi.h).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution / linear:  out[m][n] = alpha * sum_k A(m,k) * W[n][k] + bias[n] (+ res[m][n])
+//   A(m,k): NHWC gather from up to two concatenated sources (x1: channels [0,C1), x2: [C1,C1+C2)); m=(b,yo,xo),
+//   k=(tap,c) with tap=(r,s) for 3x3; optional nearest-2x upsample folded into the address map; zero padding.
+//   W: [N][K] fp16, K = ksize*ksize*(C1+C2), tap-major (KRSC).
+// Columns n >= vt_col0 are written transposed per batch item into outT (fp16 or fp32):
+//   outT[(b*(N-vt_col0) + (n-vt_col0))*vt_ld + (m % rows_per_batch)]   -- used for V^T (attention) and NCHW fp32 outputs.
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmP {
+  const half_t* x1; const half_t* x2;
+  int C1, C2, ldx1, ldx2;
+  int B, H, W, Ho, Wo;
+  int ksize, stride, pad, ups;
+  const half_t* w; int ldw;
+  int M, N, K;
+  const float* bias;
+  const half_t* res; int ldres;
+  float alpha;
+  half_t* out; int ldo;
+  void* outT; int vt_col0, vt_ld, vt_f32, rows_per_batch;
+  float* slab; int splitk, kchunks_per_split;
+};
+void gemm_defaults(GemmP& p);
+// ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.
+int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0);
+int igemm_init();  // sets dynamic-LDS attributes once
+
+// ---------------------------------------------------------------------------------------------------------------
+// Normalisation / elementwise
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm over NHWC (two-source concat allowed). partial: [B][nchunk][G][2] fp32 scratch.
+int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps,
+                     const float* gamma, const float* beta, int silu, half_t* out, float* partial, hipStream_t st);
+int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamma, const float* beta, half_t* out,
+                     hipStream_t st);
+int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st);       // x [M][2I] -> out [M][I]
+int launch_softmax_rows(half_t* x, int M, int N, int ld, hipStream_t st);            // in place, fp32 internally
+int launch_gemv(const float* x, int K, const half_t* W, int N, const float* bias, const float* bias2, int silu_in,
+                float* out, hipStream_t st);
+// weight repack (PyTorch layouts -> fp16 KRSC / head-padded rows, fp32 vectors)
+int launch_repack_matrix(const void* src, int src_f16, int rows, int cols, int taps, half_t* dst, int dst_ld, int cin_pad,
+                         int row0, int dh, int Dp, hipStream_t st);
+int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream_t st);
+int launch_nchw_f32_to_nhwc_f16(const float* in, int B, int C, int HW, int Cp, half_t* out, hipStream_t st);
+int launch_f32_to_f16(const float* in, size_t n, half_t* out, hipStream_t st);
+int launch_img_u8_to_nhwc(const uint8_t* img, int n, int HW, int Cp, half_t* out, hipStream_t st);
+int launch_dec_to_u8(const float* nchw, int n, int HW, uint8_t* out_hwc, hipStream_t st);
+int launch_scale_f32(const float* in, size_t n, float s, float* out, hipStream_t st);
+int launch_gather_rows_f32(const float* in, const int* rows, int nrows, size_t row_elems, float* out, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnP {
+  const half_t* q; int ldq, q_off;
+  const half_t* k; int ldk, k_off;
+  const half_t* vt; int ldv;      // Vt[((row*heads + head)*Dp + d)*ldv + tok]
+  half_t* o; int ldo;             // o[(row*Nq + tok)*ldo + head*dh + d]
+  int heads, Nq, Nk, Dp, dh;
+  float scale;
+  const int* rows;                // device [nrows][4] = {out_row, q_row, k_row, v_row}
+  int nrows;
+};
+int launch_attn_flash(const AttnP& p, hipStream_t st);
+
+// Cross-attention with the Prompt-to-Prompt edit fused in (one (src,tgt) row pair per grid.z entry).
+struct CrossEditP {
+  const half_t* q; int ldq, q_off;
+  const half_t* k; int ldk, k_off;
+  const half_t* vt; int ldv;
+  half_t* o; int ldo;
+  int heads, Nq, Nk, Dp, dh;
+  float scale;
+  const int* pairs;               // device [npairs][2] = {src_row, tgt_row}
+  int npairs;
+  const half_t* mmatT;            // device [npairs][96][96] fp16: mmatT[j][w] = Mmat[w][j] (zero padded)
+  const float* c1; const float* c2;   // device [npairs][96] blend coefficients for the current step
+  const float* lb_alpha;          // device [npairs][2][96] LocalBlend token selectors (nullable)
+  float* lb_acc;                  // device [npairs][nslots][2][Nq] accumulators (nullable)
+  int lb_slot0, lb_nslots;        // this layer's first slot (slot = lb_slot0 + head)
+};
+int launch_attn_cross_edit(const CrossEditP& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Scheduler / latent step kernels (fp32, NCHW, bit-exact w.r.t. the reference's elementwise order)
+// ---------------------------------------------------------------------------------------------------------------
+// x_next = sqrt(a_next) * ((x - sqrt(1-a_t) * eps) / sqrt(a_t)) + sqrt(1-a_next) * eps
+int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to, size_t n, float* out, hipStream_t st);
+// Classifier-free guidance + DDIM denoise step (+ direct-inversion offset). See include/pnpi.h pnpi_cfg_ddim_prev.
+int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale,
+                         float a_t, float a_prev, const float* noise_loss, int offset_rows, const float* target,
+                         float* offset_out, float* x_out, hipStream_t st);
+int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents,
+                       int nimg, hipStream_t st);

@@ -1,0 +1,147 @@
+// Latent-space step kernels: DDIM invert / denoise update, classifier-free guidance, the direct-inversion "3 lines",
+// and LocalBlend. fp32 NCHW latents, coalesced, wavefront-uniform scalars; every multiply/add is an explicit
+// round-to-nearest op in the reference's order (no FMA contraction), so these kernels are bit-exact against the
+// reference formulas given the same eps.
+//
+// Reference: DirectInversion.next_step models/p2p/inversion.py:262-270, prev_step :247-260,
+//   DDIMSchedulerDev.step models/p2p/scheduler_dev.py:38-95 (eta = 0, epsilon prediction, no clipping),
+//   CFG + offset lines inversion.py:383-389 and p2p_guidance_forward.py:110-114,
+//   LocalBlend.__call__/get_mask models/p2p/attention_control.py:97-121.
+#include "ops.h"
+
+__device__ __forceinline__ float ddim_update(float x, float e, float sqrt_a_from, float sqrt_b_from, float sqrt_a_to,
+                                             float sqrt_b_to) {
+  // pred_x0 = (x - sqrt(1-a_from) * e) / sqrt(a_from);  dir = sqrt(1-a_to) * e;  out = sqrt(a_to) * pred_x0 + dir
+  float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(sqrt_b_from, e)), sqrt_a_from);
+  float dir = __fmul_rn(sqrt_b_to, e);
+  return __fadd_rn(__fmul_rn(sqrt_a_to, x0), dir);
+}
+
+__global__ void ddim_move_kernel(const float* __restrict__ x, const float* __restrict__ eps, float sa_f, float sb_f, float sa_t,
+                                 float sb_t, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ddim_update(x[i], eps[i], sa_f, sb_f, sa_t, sb_t);
+}
+
+int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to, size_t n, float* out, hipStream_t st) {
+  // torch computes `t ** 0.5` on 0-dim fp32 tensors: correctly rounded fp32 sqrt of fp32 operands
+  float sa_f = sqrtf(a_from), sb_f = sqrtf(1.0f - a_from), sa_t = sqrtf(a_to), sb_t = sqrtf(1.0f - a_to);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  ddim_move_kernel<<<blocks, 256, 0, st>>>(x, eps, sa_f, sb_f, sa_t, sb_t, n, out);
+  return (int)hipGetLastError();
+}
+
+// eps: [nimg][2R][E] (first R rows unconditional, next R conditional); x: [nimg][R][E]
+//   e   = eps_u + g * (eps_c - eps_u)
+//   prev = ddim(x, e)
+//   target != null  (offset_calculate):  loss = target[img] - prev ; offset_out = loss ; x_out = prev + loss
+//   else noise_loss != null            :  x_out = prev + noise_loss[img][r]  for r < offset_rows, prev otherwise
+__global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float* __restrict__ x, int nimg, int R, size_t E, float g,
+                                     float sa_f, float sb_f, float sa_t, float sb_t, const float* __restrict__ noise_loss,
+                                     int offset_rows, const float* __restrict__ target, float* __restrict__ offset_out,
+                                     float* __restrict__ x_out) {
+  const size_t total = (size_t)nimg * R * E;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t e_idx = i % E;
+    size_t ir = i / E;
+    int r = (int)(ir % R);
+    int img = (int)(ir / R);
+    float eu = eps[((size_t)img * 2 * R + r) * E + e_idx];
+    float ec = eps[((size_t)img * 2 * R + R + r) * E + e_idx];
+    float e = __fadd_rn(eu, __fmul_rn(g, __fsub_rn(ec, eu)));
+    float prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
+    float outv = prev;
+    if (target) {
+      float loss = __fsub_rn(target[(size_t)img * E + e_idx], prev);
+      offset_out[i] = loss;
+      outv = __fadd_rn(prev, loss);
+    } else if (noise_loss && r < offset_rows) {
+      outv = __fadd_rn(prev, noise_loss[i]);
+    }
+    x_out[i] = outv;
+  }
+}
+
+int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale, float a_t,
+                         float a_prev, const float* noise_loss, int offset_rows, const float* target, float* offset_out,
+                         float* x_out, hipStream_t st) {
+  float sa_f = sqrtf(a_t), sb_f = sqrtf(1.0f - a_t), sa_t = sqrtf(a_prev), sb_t = sqrtf(1.0f - a_prev);
+  size_t total = (size_t)nimg * rows_per_img * row_elems;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  cfg_ddim_prev_kernel<<<blocks, 256, 0, st>>>(eps, x, nimg, rows_per_img, row_elems, gscale, sa_f, sb_f, sa_t, sb_t, noise_loss,
+                                               offset_rows, target, offset_out, x_out);
+  return (int)hipGetLastError();
+}
+
+// One block per image. lb_acc: [nimg][nslots][2][map_hw*map_hw] accumulated (summed over steps) selector-weighted maps.
+// maps -> mean over slots -> 3x3 max-pool (stride 1, pad 1) -> nearest resize to lat_hw -> / max -> > th
+// mask_tgt = mask_src | mask_tgt ;  x_tgt = x_src + mask_tgt * (x_tgt - x_src)   (latents [nimg][2][C][lat_hw^2])
+__global__ void __launch_bounds__(256) local_blend_kernel(const float* __restrict__ lb_acc, int nslots, int mhw, int lhw, int C,
+                                                          float th, float* __restrict__ latents) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_map = reinterpret_cast<float*>(smem_raw);  // [2][mhw*mhw]
+  float* s_pool = s_map + 2 * mhw * mhw;              // [2][mhw*mhw]
+  float* s_red = s_pool + 2 * mhw * mhw;              // [2][256]
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int MP = mhw * mhw;
+  for (int idx = tid; idx < 2 * MP; idx += blockDim.x) {
+    int which = idx / MP, pix = idx - which * MP;
+    float s = 0.f;
+    for (int sl = 0; sl < nslots; ++sl) s += lb_acc[(((size_t)img * nslots + sl) * 2 + which) * MP + pix];
+    s_map[idx] = s / (float)nslots;
+  }
+  __syncthreads();
+  float lmax[2] = {-INFINITY, -INFINITY};
+  for (int idx = tid; idx < 2 * MP; idx += blockDim.x) {
+    int which = idx / MP, pix = idx - which * MP;
+    int y = pix / mhw, x = pix - y * mhw;
+    float m = -INFINITY;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < mhw && xx >= 0 && xx < mhw) m = fmaxf(m, s_map[which * MP + yy * mhw + xx]);
+      }
+    s_pool[idx] = m;
+    lmax[which] = fmaxf(lmax[which], m);
+  }
+  s_red[tid] = lmax[0];
+  s_red[256 + tid] = lmax[1];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+      s_red[tid] = fmaxf(s_red[tid], s_red[tid + off]);
+      s_red[256 + tid] = fmaxf(s_red[256 + tid], s_red[256 + tid + off]);
+    }
+    __syncthreads();
+  }
+  const float mx0 = s_red[0], mx1 = s_red[256];
+  const int LP = lhw * lhw;
+  float* xs = latents + (size_t)img * 2 * C * LP;
+  float* xt = xs + (size_t)C * LP;
+  for (int pix = tid; pix < LP; pix += blockDim.x) {
+    int y = pix / lhw, x = pix - y * lhw;
+    // torch 'nearest': src = floor(dst * in / out)
+    int sy = (int)floorf((float)y * ((float)mhw / (float)lhw)), sx = (int)floorf((float)x * ((float)mhw / (float)lhw));
+    if (sy > mhw - 1) sy = mhw - 1;
+    if (sx > mhw - 1) sx = mhw - 1;
+    float v0 = __fdiv_rn(s_pool[sy * mhw + sx], mx0);
+    float v1 = __fdiv_rn(s_pool[MP + sy * mhw + sx], mx1);
+    bool m = (v0 > th) || (v1 > th);
+    float mf = m ? 1.f : 0.f;
+    for (int c = 0; c < C; ++c) {
+      float a = xs[(size_t)c * LP + pix], b = xt[(size_t)c * LP + pix];
+      xt[(size_t)c * LP + pix] = __fadd_rn(a, __fmul_rn(mf, __fsub_rn(b, a)));
+    }
+  }
+}
+
+int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents, int nimg,
+                       hipStream_t st) {
+  size_t lds = (size_t)(4 * map_hw * map_hw + 512) * sizeof(float);
+  local_blend_kernel<<<nimg, 256, lds, st>>>(lb_acc, nslots, map_hw, lat_hw, C, th, latents);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,324 @@
+"""Per-kernel parity: every hand-written HIP kernel against a plain PyTorch fp32 reference of the same op, through the C ABI.
+Tolerances: inputs are fp16-representable, accumulation is fp32, outputs are rounded to fp16 once ->
+rel-L2 <= 2e-3 (GEMM-like), <= 3e-3 (attention: P is rounded to fp16 before the second MFMA)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import Ctx, ptr, rel_err, max_err  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Ctx()
+    yield c
+    c.close()
+
+
+def h16(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,cfg,split", [
+    (256, 256, 128, 0, 0), (256, 256, 128, 1, 0), (256, 256, 512, 2, 4),
+    (130, 70, 72, -1, 0), (4096, 320, 320, -1, 0), (308, 640, 768, -1, 0), (64, 1280, 5120, -1, 0),
+    (1, 8, 8, -1, 0), (33, 4, 2880, 1, 0), (100, 36, 1032, 2, 3),
+])
+def test_gemm(ctx, M, N, K, cfg, split):
+    a = h16(M, K, seed=1)
+    w = h16(N, K, scale=1.0 / math.sqrt(K), seed=2)
+    bias = torch.randn(N, device=DEV)
+    res = h16(M, N, seed=3)
+    ldo = (N + 3) // 4 * 4
+    out = torch.zeros(M, ldo, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, 0.5, ptr(bias), ptr(res), ptr(out), ldo, 1 << 30, None, 0, 0, 1, cfg, split)
+    ref = 0.5 * (a.float() @ w.float().t()) + bias + res.float()
+    assert rel_err(out[:, :N], ref) < 2e-3, (rel_err(out[:, :N], ref), max_err(out[:, :N], ref))
+
+
+def test_gemm_transposed_region(ctx):
+    # QKV-style: columns [0, 128) plain, columns [128, 192) written transposed per batch item (V^T), tokens = 40 per item
+    Bn, T, K, N, col0 = 3, 40, 64, 192, 128
+    M = Bn * T
+    a = h16(M, K, seed=4)
+    w = h16(N, K, scale=0.1, seed=5)
+    out = torch.zeros(M, col0, dtype=torch.half, device=DEV)
+    vt = torch.zeros(Bn, N - col0, T, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, 1.0, None, None, ptr(out), col0, col0, ptr(vt), T, 0, T, -1, 0)
+    ref = a.float() @ w.float().t()
+    assert rel_err(out, ref[:, :col0]) < 2e-3
+    ref_vt = ref[:, col0:].reshape(Bn, T, N - col0).permute(0, 2, 1)
+    assert rel_err(vt, ref_vt) < 2e-3
+    # fp32 NCHW output (conv_out style): everything transposed
+    o32 = torch.zeros(Bn, N, T, dtype=torch.float32, device=DEV)
+    ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, 1.0, None, None, None, N, 0, ptr(o32), T, 1, T, -1, 0)
+    assert rel_err(o32, ref.reshape(Bn, T, N).permute(0, 2, 1)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def pack_w(w):  # [N, C, kh, kw] -> [N, kh*kw*C] tap-major
+    return w.permute(0, 2, 3, 1).contiguous().reshape(w.shape[0], -1)
+
+
+@pytest.mark.parametrize("B,C1,C2,H,N,stride,pad,ups,cfg,split", [
+    (2, 64, 0, 16, 64, 1, 1, 0, -1, 0),       # fast-K path
+    (2, 64, 64, 16, 128, 1, 1, 0, 0, 0),      # concat, 128x128 tile
+    (1, 320, 0, 32, 320, 1, 1, 0, -1, 0),     # SD shape, FASTK
+    (2, 32, 0, 16, 64, 1, 1, 0, -1, 0),       # Cin not a multiple of 64 -> generic K path
+    (2, 8, 0, 16, 32, 1, 1, 0, -1, 0),        # conv_in style (4 channels padded to 8)
+    (2, 64, 0, 16, 64, 2, 1, 0, -1, 0),       # UNet downsample (symmetric pad)
+    (2, 64, 0, 16, 64, 2, 0, 0, -1, 0),       # VAE downsample (pad (0,1,0,1))
+    (2, 64, 0, 8, 64, 1, 1, 1, -1, 0),        # nearest-2x upsample folded into the conv
+    (4, 1280, 0, 8, 128, 1, 1, 0, 2, 4),      # deep K, split-K
+    (2, 128, 64, 8, 4, 1, 1, 0, -1, 0),       # tiny N (conv_out style), concat with generic... C1=128 fast
+])
+def test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
+    W = H
+    x1 = h16(B, C1, H, W, seed=6)
+    x2 = h16(B, C2, H, W, seed=7) if C2 else None
+    Cin = C1 + C2
+    w = h16(N, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin), seed=8)
+    bias = torch.randn(N, device=DEV)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    xr = xin.float()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    if stride == 2 and pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+        ref = F.conv2d(xr, w.float(), bias, stride=2, padding=0)
+    else:
+        ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = h16(B, N, Ho, Wo, seed=9)
+    ref = ref + res.float()
+    out = torch.zeros(B, Ho, Wo, N, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_conv", ptr(nhwc(x1)), ptr(nhwc(x2)) if C2 else None, C1, C2, B, H, W, 3, stride, pad, ups, Ho, Wo,
+             ptr(pack_w(w)), ptr(bias), ptr(nhwc(res)), N, ptr(out), cfg, split)
+    got = out.permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 2e-3, (rel_err(got, ref), max_err(got, ref))
+
+
+def test_conv1x1_concat(ctx):
+    B, C1, C2, H, N = 2, 128, 64, 8, 96
+    x1, x2 = h16(B, C1, H, H, seed=10), h16(B, C2, H, H, seed=11)
+    w = h16(N, C1 + C2, 1, 1, scale=0.08, seed=12)
+    bias = torch.randn(N, device=DEV)
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), w.float(), bias)
+    out = torch.zeros(B, H, H, N, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_conv", ptr(nhwc(x1)), ptr(nhwc(x2)), C1, C2, B, H, H, 1, 1, 0, 0, H, H, ptr(pack_w(w)), ptr(bias), None, N,
+             ptr(out), -1, 0)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ norms / elementwise
+@pytest.mark.parametrize("B,C1,C2,HW,silu,eps", [(2, 320, 0, 256, 1, 1e-5), (2, 64, 32, 64, 1, 1e-6), (3, 32, 0, 16, 0, 1e-6),
+                                                 (1, 1280, 1280, 64, 1, 1e-5), (1, 128, 0, 4096, 1, 1e-6)])
+def test_groupnorm(ctx, B, C1, C2, HW, silu, eps):
+    C = C1 + C2
+    x1 = (h16(B, HW, C1, seed=13).float() * 2 + 0.5).half()
+    x2 = h16(B, HW, C2, seed=14) if C2 else None
+    gamma = torch.randn(C, device=DEV) * 0.2 + 1
+    beta = torch.randn(C, device=DEV) * 0.2
+    out = torch.zeros(B, HW, C, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_groupnorm", ptr(x1), ptr(x2) if C2 else None, C1, C2, B, HW, 32, eps, ptr(gamma), ptr(beta), silu, ptr(out))
+    xin = x1 if x2 is None else torch.cat([x1, x2], 2)
+    ref = F.group_norm(xin.float().permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_err(out.permute(0, 2, 1), ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,C", [(1024, 320), (100, 1280), (7, 32), (64, 640)])
+def test_layernorm(ctx, M, C):
+    x = (h16(M, C, seed=15).float() * 3 + 1).half()
+    gamma = torch.randn(C, device=DEV) * 0.2 + 1
+    beta = torch.randn(C, device=DEV) * 0.2
+    out = torch.zeros(M, C, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_layernorm", ptr(x), M, C, 1e-5, ptr(gamma), ptr(beta), ptr(out))
+    assert rel_err(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)) < 2e-3
+
+
+def test_geglu(ctx):
+    M, I = 333, 256
+    x = h16(M, 2 * I, scale=2.0, seed=16)
+    out = torch.zeros(M, I, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_geglu", ptr(x), M, I, ptr(out))
+    a, g = x.float().chunk(2, dim=-1)
+    assert rel_err(out, a * F.gelu(g)) < 2e-3
+
+
+def test_softmax_rows(ctx):
+    M, N = 37, 4096
+    x = h16(M, N, scale=3.0, seed=17)
+    ref = x.float().softmax(-1)
+    ctx.call("pnpi_op_softmax_rows", ptr(x), M, N, N)
+    assert rel_err(x, ref) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def make_qkv(B, heads, Nq, Nk, dh, Dp, seed):
+    q = h16(B, heads, Nq, dh, seed=seed)
+    k = h16(B, heads, Nk, dh, seed=seed + 1)
+    v = h16(B, heads, Nk, dh, seed=seed + 2)
+    hd = heads * Dp
+    qb = torch.zeros(B, Nq, hd, dtype=torch.half, device=DEV)
+    kb = torch.zeros(B, Nk, hd, dtype=torch.half, device=DEV)
+    ldv = (Nk + 7) // 8 * 8
+    vt = torch.full((B, heads, Dp, ldv), float("nan"), dtype=torch.half, device=DEV)  # pads are NaN on purpose
+    vt[:, :, :, :Nk] = 0
+    for h in range(heads):
+        qb[:, :, h * Dp:h * Dp + dh] = q[:, h]
+        kb[:, :, h * Dp:h * Dp + dh] = k[:, h]
+        vt[:, h, :dh, :Nk] = v[:, h].transpose(1, 2)
+    return q, k, v, qb, kb, vt, ldv
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,dh,Dp", [
+    (2, 2, 256, 256, 40, 64), (1, 2, 1024, 1024, 80, 96), (2, 8, 64, 64, 160, 160), (2, 2, 200, 77, 40, 64),
+    (1, 2, 16, 16, 8, 32), (1, 1, 100, 130, 32, 32), (1, 2, 4096, 4096, 40, 64), (2, 2, 64, 77, 160, 160), (1, 2, 96, 77, 128, 128),
+])
+def test_attention_flash(ctx, B, heads, Nq, Nk, dh, Dp):
+    q, k, v, qb, kb, vt, ldv = make_qkv(B, heads, Nq, Nk, dh, Dp, seed=20)
+    scale = dh ** -0.5
+    o = torch.zeros(B, Nq, heads * dh, dtype=torch.half, device=DEV)
+    rows = torch.arange(B, dtype=torch.int32, device=DEV).repeat_interleave(4).reshape(B, 4).contiguous()
+    ctx.call("pnpi_op_attention", ptr(qb), heads * Dp, 0, ptr(kb), heads * Dp, 0, ptr(vt), ldv, ptr(o), heads * dh, heads, Nq, Nk,
+             Dp, dh, scale, ptr(rows), B)
+    ref = (q.float() @ k.float().transpose(-1, -2) * scale).softmax(-1) @ v.float()   # [B, heads, Nq, dh]
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Nq, heads * dh)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < 3e-3, (rel_err(o, ref), max_err(o, ref))
+
+
+def test_attention_row_indirection(ctx):
+    # self-attention replacement: output row 3 uses q,k of row 2 and its own v (attention_control.py:258-263)
+    B, heads, N, dh, Dp = 4, 2, 128, 40, 64
+    q, k, v, qb, kb, vt, ldv = make_qkv(B, heads, N, N, dh, Dp, seed=30)
+    scale = dh ** -0.5
+    rows = torch.tensor([[0, 0, 0, 0], [1, 1, 1, 1], [2, 2, 2, 2], [3, 2, 2, 3]], dtype=torch.int32, device=DEV)
+    o = torch.zeros(B, N, heads * dh, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_attention", ptr(qb), heads * Dp, 0, ptr(kb), heads * Dp, 0, ptr(vt), ldv, ptr(o), heads * dh, heads, N, N, Dp,
+             dh, scale, ptr(rows), B)
+    p = (q.float() @ k.float().transpose(-1, -2) * scale).softmax(-1)
+    p[3] = p[2]
+    ref = (p @ v.float()).permute(0, 2, 1, 3).reshape(B, N, heads * dh)
+    assert rel_err(o, ref) < 3e-3
+
+
+@pytest.mark.parametrize("Nq,dh,Dp,with_lb", [(256, 160, 160, True), (1024, 80, 96, False), (4096, 40, 64, False), (64, 8, 32, True)])
+def test_cross_edit(ctx, Nq, dh, Dp, with_lb):
+    # rows: [unc_src, unc_tgt, cond_src, cond_tgt]; the kernel handles the pair (2, 3)
+    B, heads, Nk = 4, 2, 77
+    q, k, v, qb, kb, vt, ldv = make_qkv(B, heads, Nq, Nk, dh, Dp, seed=40)
+    scale = dh ** -0.5
+    g = torch.Generator().manual_seed(5)
+    mm = torch.eye(77)
+    mm[3, 3] = 0; mm[3, 4] = 0.5; mm[3, 5] = 0.5; mm[10] = 0; mm[10, 76] = 1.0    # some non-trivial mapping
+    c1 = torch.rand(96, generator=g); c2 = torch.rand(96, generator=g)
+    lba = torch.zeros(2, 96); lba[0, 2] = 1; lba[1, 2] = 1; lba[1, 3] = 1
+    mmT = torch.zeros(96, 96); mmT[:77, :77] = mm.t()
+    mmT16 = mmT.half().to(DEV).contiguous()
+    pairs = torch.tensor([[2, 3]], dtype=torch.int32, device=DEV)
+    nslots = 2 * heads
+    lb_acc = torch.ones(1, nslots, 2, Nq, device=DEV)
+    o = torch.zeros(B, Nq, heads * dh, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_cross_edit", ptr(qb), heads * Dp, 0, ptr(kb), heads * Dp, 0, ptr(vt), ldv, ptr(o), heads * dh, heads, Nq, Nk, Dp,
+             dh, scale, ptr(pairs), 1, ptr(mmT16), ptr(c1.to(DEV)), ptr(c2.to(DEV)), ptr(lba.to(DEV).contiguous()) if with_lb else None,
+             ptr(lb_acc) if with_lb else None, heads, nslots)
+    p = (q.float() @ k.float().transpose(-1, -2) * scale).softmax(-1)        # [B, heads, Nq, 77]
+    psrc, ptgt = p[2], p[3]
+    mapped = psrc @ mm.to(DEV)
+    pnew = c1[:77].to(DEV) * mapped + c2[:77].to(DEV) * ptgt
+    ref_src = (psrc @ v[2].float()).permute(1, 0, 2).reshape(Nq, heads * dh)
+    ref_tgt = (pnew @ v[3].float()).permute(1, 0, 2).reshape(Nq, heads * dh)
+    assert rel_err(o[2], ref_src) < 3e-3, rel_err(o[2], ref_src)
+    assert rel_err(o[3], ref_tgt) < 4e-3, rel_err(o[3], ref_tgt)
+    assert o[0].abs().max() == 0 and o[1].abs().max() == 0        # rows outside the pair are not touched
+    if with_lb:
+        la = lba[:, :77].to(DEV)
+        exp_src = 1 + (psrc * la[0]).sum(-1)      # [heads, Nq]
+        exp_tgt = 1 + (pnew * la[1]).sum(-1)
+        got = lb_acc[0, heads:2 * heads]           # slots lb_slot0 + head
+        assert rel_err(got[:, 0], exp_src) < 3e-3
+        assert rel_err(got[:, 1], exp_tgt) < 3e-3
+        assert (lb_acc[0, :heads] == 1).all()
+
+
+# ------------------------------------------------------------------------------------------------ step kernels (bit exact)
+def ref_alphas():
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def test_step_kernels_bit_exact(ctx):
+    ac = ref_alphas()
+    final = ac[0]
+    arr = (C.c_float * 1000)(*ac.tolist())
+    ctx.call("pnpi_set_scheduler", arr, 1000, float(final))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    e4 = torch.randn(4, 4, 16, 16, generator=g)
+    for t in (980, 500, 20, 0):
+        # next_step (inversion.py:262-270)
+        tp = min(t - 20, 999)
+        a_t = ac[tp] if tp >= 0 else final
+        a_n = ac[t]
+        e = e4[:2]
+        x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+        ref = a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * e
+        out = torch.empty_like(x, device=DEV)
+        ctx.call("pnpi_ddim_next_step", ptr(e.contiguous().to(DEV)), t, 20, ptr(x.to(DEV)), x.numel(), ptr(out))
+        assert torch.equal(out.cpu(), ref), t
+        # CFG + prev_step + offset (inversion.py:383-389)
+        a_t = ac[t]
+        a_p = ac[t - 20] if t - 20 >= 0 else final
+        eu, ec = e4.chunk(2)
+        eg = eu + 7.5 * (ec - eu)
+        x0 = (x - (1 - a_t) ** 0.5 * eg) / a_t ** 0.5
+        prev = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eg
+        target = torch.randn(1, 4, 16, 16, generator=g)
+        loss = target - prev
+        cur = prev + loss
+        off = torch.empty(2, 4, 16, 16, device=DEV)
+        xo = torch.empty(2, 4, 16, 16, device=DEV)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4.to(DEV)), ptr(x.to(DEV)), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(target.to(DEV)),
+                 ptr(off), ptr(xo))
+        assert torch.equal(off.cpu(), loss) and torch.equal(xo.cpu(), cur), t
+        # guidance step with noise_loss on the first row only (p2p_guidance_forward.py:110-114)
+        nl = torch.randn(2, 4, 16, 16, generator=g)
+        ref2 = torch.cat((prev[:1] + nl[:1], prev[1:]))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4.to(DEV)), ptr(x.to(DEV)), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nl.to(DEV)), 1, None, None,
+                 ptr(xo))
+        assert torch.equal(xo.cpu(), ref2), t
+
+
+def test_local_blend(ctx):
+    nslots, mhw, lhw, Cc = 6, 16, 64, 4
+    g = torch.Generator().manual_seed(3)
+    acc = torch.rand(1, nslots, 2, mhw * mhw, generator=g)
+    lat = torch.randn(1, 2, Cc, lhw, lhw, generator=g)
+    d_lat = lat.clone().to(DEV)
+    ctx.call("pnpi_op_local_blend", ptr(acc.to(DEV)), nslots, mhw, lhw, Cc, 0.3, ptr(d_lat), 1)
+    # LocalBlend.get_mask / __call__ (attention_control.py:97-121)
+    maps = acc[0].permute(1, 0, 2).reshape(2, nslots, 1, mhw, mhw).mean(1)
+    m = F.max_pool2d(maps, (3, 3), (1, 1), padding=(1, 1))
+    m = F.interpolate(m, size=(lhw, lhw))
+    m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
+    m = m.gt(0.3)
+    m = m[:1] + m
+    x_t = lat[0]
+    ref = x_t[:1] + m.float() * (x_t - x_t[:1])
+    assert torch.equal(d_lat.cpu()[0], ref)
