@@ -1,0 +1,236 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the direct-inversion + Prompt-to-Prompt loop: scheduler tables, DDIM moves,
+the three DI lines, the attention controllers and LocalBlend, restated in plain PyTorch/numpy from
+
+  models/p2p/inversion.py:245-400          (DirectInversion: next_step, prev_step, ddim_loop, offset_calculate)
+  models/p2p/p2p_guidance_forward.py:103-173 (direct_inversion_p2p_guidance_{diffusion_step,forward})
+  models/p2p/scheduler_dev.py:38-95        (DDIMSchedulerDev.step, eta = 0)
+  models/p2p/attention_control.py:95-363   (LocalBlend, AttentionStore, AttentionControlEdit, Replace/Refine/Reweight)
+  utils/utils.py:58-80                     (latent2image, image2latent)
+
+Scalars: the reference evaluates `alpha ** 0.5` on 0-dim fp32 tensors; torch's CPU pow is 1 ulp off a correctly rounded
+sqrt on some hosts, so this oracle (like the HIP kernels) pins the IEEE answer: correctly rounded fp32 sqrt.
+Pinned against the reference's own code by oracle/make_golden.py -> tests/golden/ (see tests/test_oracle_golden.py)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MAX_NUM_WORDS = 77
+
+
+# ----------------------------------------------------------------------------------------------------- scheduler tables
+def alphas_cumprod(n_train=1000, beta_start=0.00085, beta_end=0.012):
+    """DDIMScheduler(beta_schedule="scaled_linear") tables as built in models/p2p_editor.py:18-22 (diffusers 0.10.0)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n_train, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def make_timesteps(num_inference_steps, n_train=1000):
+    ratio = n_train // num_inference_steps
+    return (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+
+
+def _scalars(a_from, a_to, dtype):
+    if dtype == torch.float32:
+        f = np.float32
+        af, at = f(a_from), f(a_to)
+        return float(np.sqrt(af)), float(np.sqrt(f(1) - af)), float(np.sqrt(at)), float(np.sqrt(f(1) - at))
+    af, at = float(a_from), float(a_to)
+    return af ** 0.5, (1 - af) ** 0.5, at ** 0.5, (1 - at) ** 0.5
+
+
+def ddim_move(x, eps, a_from, a_to):
+    """x_to = sqrt(a_to) * (x - sqrt(1-a_from) eps) / sqrt(a_from) + sqrt(1-a_to) eps   (inversion.py:251-253, 266-269)."""
+    sa_f, sb_f, sa_t, sb_t = _scalars(a_from, a_to, x.dtype)
+    x0 = (x - sb_f * eps) / sa_f
+    return sa_t * x0 + sb_t * eps
+
+
+def next_alphas(ac, final, t, ratio):
+    tp = min(t - ratio, 999)
+    return (ac[tp] if tp >= 0 else final), ac[t]
+
+
+def prev_alphas(ac, final, t, ratio):
+    tp = t - ratio
+    return ac[t], (ac[tp] if tp >= 0 else final)
+
+
+# ----------------------------------------------------------------------------------------------------- controllers
+class StoreController:
+    """AttentionStore (attention_control.py:214-248): keeps the conditional half of every <= 32^2-token map, summed over steps."""
+
+    def __init__(self, num_att_layers):
+        self.num_att_layers = num_att_layers
+        self.cur_step = 0
+        self.cur_att_layer = 0
+        self.step_store = self._empty()
+        self.attention_store = {}
+
+    @staticmethod
+    def _empty():
+        return {"down_cross": [], "mid_cross": [], "up_cross": [], "down_self": [], "mid_self": [], "up_self": []}
+
+    def edit(self, attn, is_cross, place):
+        return attn
+
+    def __call__(self, attn, is_cross, place):
+        h = attn.shape[0]
+        cond = self.edit(attn[h // 2:], is_cross, place)
+        if cond.shape[1] <= 32 ** 2:
+            self.step_store["%s_%s" % (place, "cross" if is_cross else "self")].append(cond)
+        attn = torch.cat([attn[: h // 2], cond], dim=0)
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            if not self.attention_store:
+                self.attention_store = self.step_store
+            else:
+                for k in self.attention_store:
+                    for i in range(len(self.attention_store[k])):
+                        self.attention_store[k][i] = self.attention_store[k][i] + self.step_store[k][i]
+            self.step_store = self._empty()
+        return attn
+
+    def step_callback(self, x_t):
+        return x_t
+
+
+class EditController(StoreController):
+    """AttentionControlEdit.forward (:269-282) with AttentionReplace (:303-304), AttentionRefine (:319-323),
+    AttentionReweight (:340-345) and LocalBlend (:97-121).  `tables` are the host tables of make_controller (:366-405):
+      cross_alpha [steps+1, 77]; kind "replace" (mapper [77,77]) or "refine" (mapper [77] int64, alphas [77]) or "none";
+      equalizer [77] or None; self_range (lo, hi); lb = dict(alpha_layers [2,77], start, th) or None."""
+
+    def __init__(self, num_att_layers, tables, batch_size=2):
+        super().__init__(num_att_layers)
+        self.t = tables
+        self.batch_size = batch_size
+        self.lb_counter = 0
+
+    def _replace_cross(self, base, repl):
+        t = self.t
+        if t["kind"] == "replace":
+            out = torch.einsum("hpw,bwn->bhpn", base, t["mapper"].to(base.dtype)[None])
+        elif t["kind"] == "refine":
+            gathered = base[:, :, t["mapper"][None]].permute(2, 0, 1, 3)
+            al = t["alphas"].to(base.dtype).reshape(1, 1, 1, -1)
+            out = gathered * al + repl * (1 - al)
+        else:
+            out = base[None]
+        if t.get("equalizer") is not None:
+            # AttentionReweight: attn_base[None] * equalizer[:, None, None, :]; the blend keeps the extra leading dim and the
+            # assignment broadcasts it back
+            out = out.reshape(-1, *out.shape[-3:]) * t["equalizer"].to(base.dtype).reshape(1, 1, 1, -1)
+        return out
+
+    def edit(self, attn, is_cross, place):
+        lo, hi = self.t["self_range"]
+        if is_cross or (lo <= self.cur_step < hi):
+            h = attn.shape[0] // self.batch_size
+            a = attn.reshape(self.batch_size, h, *attn.shape[1:])
+            base, repl = a[0], a[1:]
+            if is_cross:
+                aw = self.t["cross_alpha"][self.cur_step].to(attn.dtype).reshape(1, 1, 1, -1)
+                new = self._replace_cross(base, repl) * aw + (1 - aw) * repl
+            else:
+                new = base[None].expand_as(repl) if repl.shape[2] <= 32 ** 2 else repl
+            attn = torch.cat([base[None], new], dim=0).reshape(self.batch_size * h, *attn.shape[1:])
+        return attn
+
+    def local_blend_mask(self, x_t):
+        lb = self.t["lb"]
+        maps = self.attention_store["down_cross"][2:4] + self.attention_store["up_cross"][:3]
+        al = lb["alpha_layers"].to(x_t.dtype).reshape(2, 1, 1, 1, 1, MAX_NUM_WORDS)
+        maps = [m.reshape(2, -1, 1, 16, 16, MAX_NUM_WORDS) for m in maps]
+        maps = torch.cat(maps, dim=1)
+        m = (maps * al).sum(-1).mean(1)
+        m = F.max_pool2d(m, (3, 3), (1, 1), padding=(1, 1))
+        m = F.interpolate(m, size=x_t.shape[2:])
+        m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
+        m = m.gt(lb["th"])
+        return m[:1] + m
+
+    def step_callback(self, x_t):
+        lb = self.t.get("lb")
+        if lb is not None:
+            self.lb_counter += 1
+            if self.lb_counter > lb["start"]:
+                mask = self.local_blend_mask(x_t).to(x_t.dtype)
+                x_t = x_t[:1] + mask * (x_t - x_t[:1])
+        return x_t
+
+
+# ----------------------------------------------------------------------------------------------------- loops
+def ddim_loop(unet_fn, z0, ctx_cond, timesteps, ac, final):
+    """DirectInversion.ddim_loop (inversion.py:308-319): B = 1, conditional source embedding only, t ascending."""
+    n = len(timesteps)
+    ratio = len(ac) // n
+    lat = z0.clone()
+    all_lat = [z0]
+    for i in range(n):
+        t = int(timesteps[n - i - 1])
+        eps = unet_fn(lat, t, ctx_cond, None)
+        a_from, a_to = next_alphas(ac, final, t, ratio)
+        lat = ddim_move(lat, eps, float(a_from), float(a_to))
+        all_lat.append(lat)
+    return all_lat
+
+
+def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guidance_scale):
+    """DirectInversion.offset_calculate (inversion.py:375-391).  context4 rows = [unc_src, unc_tgt, cond_src, cond_tgt]."""
+    n = len(timesteps)
+    ratio = len(ac) // n
+    nrow = context4.shape[0] // 2
+    cur = torch.cat([ddim_latents[-1]] * nrow)
+    losses = []
+    for i in range(n):
+        prev_target = torch.cat([ddim_latents[len(ddim_latents) - i - 2]] * cur.shape[0])
+        t = int(timesteps[i])
+        eps = unet_fn(torch.cat([cur] * 2), t, context4, None)
+        eu, ec = eps.chunk(2)
+        e = eu + guidance_scale * (ec - eu)
+        a_t, a_p = prev_alphas(ac, final, t, ratio)
+        prev_rec = ddim_move(cur, e, float(a_t), float(a_p))
+        loss = prev_target - prev_rec
+        losses.append(loss)
+        cur = prev_rec + loss
+    return losses
+
+
+def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timesteps, ac, final, guidance_scale, offset_rows=1,
+                     collect=None):
+    """direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) + ..._diffusion_step (:103-116)."""
+    n = len(timesteps)
+    ratio = len(ac) // n
+    nrow = context4.shape[0] // 2
+    lat = x_T.expand(nrow, *x_T.shape[1:]).clone()
+    for i in range(n):
+        t = int(timesteps[i])
+        eps = unet_fn(torch.cat([lat] * 2), t, context4, controller)
+        eu, ec = eps.chunk(2)
+        e = eu + guidance_scale * (ec - eu)
+        a_t, a_p = prev_alphas(ac, final, t, ratio)
+        lat = ddim_move(lat, e, float(a_t), float(a_p))
+        if noise_loss_list is not None:
+            lat = torch.cat((lat[:offset_rows] + noise_loss_list[i][:offset_rows], lat[offset_rows:]))
+        if controller is not None:
+            lat = controller.step_callback(lat)
+        if collect is not None:
+            collect.append(lat.clone())
+    return lat
+
+
+def image2latent(vae_encode_mean_fn, image_u8):
+    """utils/utils.py:68-80"""
+    x = torch.from_numpy(image_u8).float() / 127.5 - 1
+    x = x.permute(2, 0, 1).unsqueeze(0)
+    return vae_encode_mean_fn(x) * 0.18215
+
+
+def latent2image(vae_decode_fn, latents):
+    """utils/utils.py:58-66"""
+    x = vae_decode_fn(1 / 0.18215 * latents)
+    x = (x / 2 + 0.5).clamp(0, 1)
+    x = x.permute(0, 2, 3, 1).numpy()
+    return (x * 255).astype(np.uint8)

@@ -9,6 +9,10 @@
 //   LocalBlend.__call__/get_mask models/p2p/attention_control.py:97-121.
 #include "ops.h"
 
+// The reference evaluates each multiply / add / divide as a separately rounded fp32 op (eager PyTorch).  hipcc would
+// contract a*b+c into one FMA (single rounding) by default, so contraction is switched off for this file.
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ float ddim_update(float x, float e, float sqrt_a_from, float sqrt_b_from, float sqrt_a_to,
                                              float sqrt_b_to) {
   // pred_x0 = (x - sqrt(1-a_from) * e) / sqrt(a_from);  dir = sqrt(1-a_to) * e;  out = sqrt(a_to) * pred_x0 + dir

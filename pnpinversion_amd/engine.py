@@ -1,0 +1,272 @@
+"""NativeEngine: thin Python owner of one pnpi_ctx (one per process / GPU).  PyTorch is used for device memory, the HIP
+stream and (elsewhere) torch.distributed only; every FLOP of the hot path runs inside libpnpi.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .config import ModelConfig
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class ControllerTables:
+    """Host tables of one image's Prompt-to-Prompt controller -> pnpi_ctrl_desc (see include/pnpi.h)."""
+
+    def __init__(self, cross_alpha, mapper, alphas, equalizer, self_range, lb_alpha=None, lb_start=0, lb_threshold=0.3,
+                 self_max_tokens=32 ** 2):
+        f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        self.cross_alpha = f(cross_alpha)      # [steps+1, 77]
+        self.mapper = f(mapper)                # [77, 77]
+        self.alphas = f(alphas)                # [77]
+        self.equalizer = f(equalizer)          # [77]
+        self.self_range = (int(self_range[0]), int(self_range[1]))
+        self.lb_alpha = f(lb_alpha) if lb_alpha is not None else None   # [2, 77]
+        self.lb_start = int(lb_start)
+        self.lb_threshold = float(lb_threshold)
+        self.self_max_tokens = int(self_max_tokens)
+
+    def desc(self):
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        d = _capi.CtrlDesc()
+        d.kind = 1
+        d.n_alpha_rows = self.cross_alpha.shape[0]
+        d.cross_alpha_host = fp(self.cross_alpha)
+        d.mapper_host = fp(self.mapper)
+        d.alphas_host = fp(self.alphas)
+        d.equalizer_host = fp(self.equalizer)
+        d.self_replace_lo, d.self_replace_hi = self.self_range
+        d.self_replace_max_tokens = self.self_max_tokens
+        d.lb_enabled = 1 if self.lb_alpha is not None else 0
+        d.lb_start = self.lb_start
+        d.lb_threshold = self.lb_threshold
+        d.lb_alpha_host = fp(self.lb_alpha) if self.lb_alpha is not None else None
+        return d
+
+
+def _desc_array(ctrls):
+    """list[ControllerTables | None] -> (ctypes array of pnpi_ctrl_desc, keep-alive)"""
+    if ctrls is None:
+        return None
+    arr = (_capi.CtrlDesc * len(ctrls))()
+    for i, c in enumerate(ctrls):
+        if c is None:
+            arr[i].kind = 0
+        else:
+            arr[i] = c.desc()
+    return arr
+
+
+class NativeEngine:
+    def __init__(self, cfg: ModelConfig, device=None, max_unet_rows=4, max_vae_images=2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeEngine needs an AMD GPU (gfx950); there is no CPU fallback")
+        self.lib = _capi.load_library()
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._ccfg = cfg.to_c()
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            st = self.lib.pnpi_create(C.byref(self.h), C.byref(self._ccfg), self.device.index or 0, C.c_void_p(stream),
+                                      max_unet_rows, max_vae_images)
+        if st != 0:
+            msg = self.lib.pnpi_last_error(self.h)
+            raise _capi.PnpiError(st, msg.decode() if msg else "?")
+        self.max_unet_rows = max_unet_rows
+        self.lat_hw = cfg.sample_size
+        self.ac = None
+        self.final_alpha = None
+
+    # ---- plumbing
+    def _call(self, name, *args):
+        st = getattr(self.lib, name)(self.h, *args)
+        _capi.check(self.lib, self.h, st)
+
+    def close(self):
+        if self.h:
+            self.lib.pnpi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _f32(self, t):
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ---- weights
+    def load_state_dict(self, unet_sd=None, vae_sd=None, chunk_bytes=1 << 30):
+        """diffusers-layout state dicts (CPU or GPU tensors, fp32 or fp16); repacked on the device into the fp16 arena."""
+        items = []
+        for prefix, sd in (("unet.", unet_sd), ("vae.", vae_sd)):
+            if sd:
+                items += [(prefix + k, v) for k, v in sd.items()]
+        batch, keep, size = [], [], 0
+
+        def flush():
+            nonlocal batch, keep, size
+            if not batch:
+                return
+            arr = (_capi.NamedTensor * len(batch))(*batch)
+            self._call("pnpi_load_weights", arr, len(batch))
+            torch.cuda.synchronize(self.device)
+            batch, keep, size = [], [], 0
+
+        for name, v in items:
+            t = v.detach()
+            if t.dtype not in (torch.float32, torch.float16):
+                t = t.float()
+            t = t.to(self.device).contiguous()
+            nt = _capi.NamedTensor()
+            nt.name = name.encode()
+            nt.data = t.data_ptr()
+            nt.dtype = 1 if t.dtype == torch.float16 else 0
+            nt.ndim = t.dim()
+            for i, s in enumerate(t.shape):
+                nt.shape[i] = s
+            batch.append(nt)
+            keep.append((t, nt.name))
+            size += t.numel() * t.element_size()
+            if size >= chunk_bytes:
+                flush()
+        flush()
+
+    def missing_weights(self):
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.pnpi_missing_weights(self.h, buf, len(buf))
+        return n, buf.value.decode().split("\n")[:-1]
+
+    def weight_arena(self):
+        """The packed weight arena as a uint8 CUDA tensor view (for the one start-up RCCL broadcast)."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        self._call("pnpi_weight_arena", C.byref(ptr), C.byref(nbytes))
+        return ptr.value, nbytes.value
+
+    def mark_all_loaded(self):
+        self._call("pnpi_mark_all_loaded")
+
+    def set_scheduler(self, alphas_cumprod, final_alpha_cumprod):
+        ac = np.ascontiguousarray(np.asarray(alphas_cumprod, dtype=np.float32))
+        self.ac = ac
+        self.final_alpha = float(np.float32(final_alpha_cumprod))
+        self._call("pnpi_set_scheduler", ac.ctypes.data_as(C.POINTER(C.c_float)), len(ac), self.final_alpha)
+
+    def counters(self):
+        c = _capi.Counters()
+        self._call("pnpi_get_counters", C.byref(c))
+        return {k: getattr(c, k) for k, _ in c._fields_}
+
+    def reset_counters(self):
+        self._call("pnpi_reset_counters")
+
+    # ---- level 1
+    def unet(self, latents, t, context, rows_per_image=1, ctrls=None, cur_step=0):
+        lat, ctx = self._f32(latents), self._f32(context)
+        rows = lat.shape[0]
+        out = torch.empty_like(lat)
+        arr = _desc_array(ctrls)
+        self._call("pnpi_unet_forward", _p(lat), rows, rows_per_image, int(t), _p(ctx), arr, int(cur_step), _p(out))
+        self._keep = (lat, ctx, arr, ctrls)
+        return out
+
+    def local_blend(self, latents, step_index):
+        lat = self._f32(latents)
+        self._call("pnpi_local_blend", _p(lat), lat.shape[0] // 2, int(step_index))
+        return lat
+
+    def vae_encode(self, x):
+        x = self._f32(x)
+        n, _, H, W = x.shape
+        f = self.cfg.vae_scale
+        out = torch.empty(n, self.cfg.vae_latent_channels, H // f, W // f, device=self.device)
+        self._call("pnpi_vae_encode", _p(x), n, H, W, _p(out))
+        self._keep = x
+        return out
+
+    def vae_decode(self, z):
+        z = self._f32(z)
+        n, _, h, w = z.shape
+        f = self.cfg.vae_scale
+        out = torch.empty(n, 3, h * f, w * f, device=self.device)
+        self._call("pnpi_vae_decode", _p(z), n, h, w, _p(out))
+        self._keep = z
+        return out
+
+    def image2latent(self, img_u8):
+        """uint8 [n,H,W,3] (or [H,W,3]) -> 0.18215 * posterior mean, fp32 [n,4,H/8,W/8]."""
+        img = torch.as_tensor(img_u8)
+        if img.dim() == 3:
+            img = img[None]
+        img = img.to(self.device).contiguous()
+        n, H, W, _ = img.shape
+        f = self.cfg.vae_scale
+        out = torch.empty(n, self.cfg.vae_latent_channels, H // f, W // f, device=self.device)
+        self._call("pnpi_image2latent", _p(img), n, H, W, _p(out))
+        self._keep = img
+        return out
+
+    def latent2image(self, z):
+        z = self._f32(z)
+        n, _, h, w = z.shape
+        f = self.cfg.vae_scale
+        out = torch.empty(n, h * f, w * f, 3, dtype=torch.uint8, device=self.device)
+        self._call("pnpi_latent2image", _p(z), n, h, w, _p(out))
+        self._keep = z
+        return out
+
+    def ddim_next_step(self, eps, t, ratio, sample):
+        e, s = self._f32(eps), self._f32(sample)
+        out = torch.empty_like(s)
+        self._call("pnpi_ddim_next_step", _p(e), int(t), int(ratio), _p(s), s.numel(), _p(out))
+        self._keep = (e, s)
+        return out
+
+    def ddim_prev_step(self, eps, t, ratio, sample):
+        e, s = self._f32(eps), self._f32(sample)
+        out = torch.empty_like(s)
+        self._call("pnpi_ddim_prev_step", _p(e), int(t), int(ratio), _p(s), s.numel(), _p(out))
+        self._keep = (e, s)
+        return out
+
+    # ---- level 2
+    def _ts(self, timesteps):
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int32))
+        return ts, ts.ctypes.data_as(C.POINTER(C.c_int))
+
+    def ddim_invert(self, z0, ctx_cond, timesteps):
+        z0, ctx = self._f32(z0), self._f32(ctx_cond)
+        n = len(timesteps)
+        nimg = z0.shape[0]
+        out = torch.empty(n + 1, *z0.shape, device=self.device)
+        ts, tsp = self._ts(timesteps)
+        self._call("pnpi_ddim_invert", _p(z0), nimg, _p(ctx), n, tsp, _p(out))
+        self._keep = (z0, ctx, ts)
+        return out
+
+    def offset_calculate(self, ddim_latents, context4, timesteps, guidance_scale):
+        lat, ctx = self._f32(ddim_latents), self._f32(context4)
+        n = len(timesteps)
+        nimg = lat.shape[1]
+        out = torch.empty(n, nimg, 2, *lat.shape[2:], device=self.device)
+        ts, tsp = self._ts(timesteps)
+        self._call("pnpi_offset_calculate", _p(lat), nimg, _p(ctx), n, tsp, float(guidance_scale), _p(out))
+        self._keep = (lat, ctx, ts)
+        return out
+
+    def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1):
+        xT, ctx = self._f32(x_T), self._f32(context4)
+        nl = self._f32(noise_loss) if noise_loss is not None else None
+        n = len(timesteps)
+        nimg = xT.shape[0]
+        out = torch.empty(nimg, 2, *xT.shape[1:], device=self.device)
+        ts, tsp = self._ts(timesteps)
+        arr = _desc_array(ctrls)
+        self._call("pnpi_edit_loop", _p(xT), nimg, _p(ctx), _p(nl), int(offset_rows), arr, n, tsp, float(guidance_scale), _p(out))
+        self._keep = (xT, ctx, nl, ts, arr, ctrls)
+        return out

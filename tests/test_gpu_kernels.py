@@ -105,8 +105,11 @@ def test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
     res = h16(B, N, Ho, Wo, seed=9)
     ref = ref + res.float()
     out = torch.zeros(B, Ho, Wo, N, dtype=torch.half, device=DEV)
-    ctx.call("pnpi_op_conv", ptr(nhwc(x1)), ptr(nhwc(x2)) if C2 else None, C1, C2, B, H, W, 3, stride, pad, ups, Ho, Wo,
-             ptr(pack_w(w)), ptr(bias), ptr(nhwc(res)), N, ptr(out), cfg, split)
+    # keep every device tensor alive in a local until the result has been read back
+    x1n, x2n, wp, resn = nhwc(x1), (nhwc(x2) if C2 else None), pack_w(w), nhwc(res)
+    ctx.call("pnpi_op_conv", ptr(x1n), ptr(x2n), C1, C2, B, H, W, 3, stride, pad, ups, Ho, Wo,
+             ptr(wp), ptr(bias), ptr(resn), N, ptr(out), cfg, split)
+    torch.cuda.synchronize()
     got = out.permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 2e-3, (rel_err(got, ref), max_err(got, ref))
 
@@ -118,8 +121,10 @@ def test_conv1x1_concat(ctx):
     bias = torch.randn(N, device=DEV)
     ref = F.conv2d(torch.cat([x1, x2], 1).float(), w.float(), bias)
     out = torch.zeros(B, H, H, N, dtype=torch.half, device=DEV)
-    ctx.call("pnpi_op_conv", ptr(nhwc(x1)), ptr(nhwc(x2)), C1, C2, B, H, H, 1, 1, 0, 0, H, H, ptr(pack_w(w)), ptr(bias), None, N,
+    x1n, x2n, wp = nhwc(x1), nhwc(x2), pack_w(w)
+    ctx.call("pnpi_op_conv", ptr(x1n), ptr(x2n), C1, C2, B, H, H, 1, 1, 0, 0, H, H, ptr(wp), ptr(bias), None, N,
              ptr(out), -1, 0)
+    torch.cuda.synchronize()
     assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-3
 
 
@@ -235,9 +240,11 @@ def test_cross_edit(ctx, Nq, dh, Dp, with_lb):
     nslots = 2 * heads
     lb_acc = torch.ones(1, nslots, 2, Nq, device=DEV)
     o = torch.zeros(B, Nq, heads * dh, dtype=torch.half, device=DEV)
+    c1d, c2d, lbad = c1.to(DEV), c2.to(DEV), lba.to(DEV).contiguous()
     ctx.call("pnpi_op_cross_edit", ptr(qb), heads * Dp, 0, ptr(kb), heads * Dp, 0, ptr(vt), ldv, ptr(o), heads * dh, heads, Nq, Nk, Dp,
-             dh, scale, ptr(pairs), 1, ptr(mmT16), ptr(c1.to(DEV)), ptr(c2.to(DEV)), ptr(lba.to(DEV).contiguous()) if with_lb else None,
+             dh, scale, ptr(pairs), 1, ptr(mmT16), ptr(c1d), ptr(c2d), ptr(lbad) if with_lb else None,
              ptr(lb_acc) if with_lb else None, heads, nslots)
+    torch.cuda.synchronize()
     p = (q.float() @ k.float().transpose(-1, -2) * scale).softmax(-1)        # [B, heads, Nq, 77]
     psrc, ptgt = p[2], p[3]
     mapped = psrc @ mm.to(DEV)
@@ -271,6 +278,7 @@ def test_step_kernels_bit_exact(ctx):
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 4, 16, 16, generator=g)
     e4 = torch.randn(4, 4, 16, 16, generator=g)
+    xd, e4d = x.to(DEV), e4.to(DEV)
     for t in (980, 500, 20, 0):
         # next_step (inversion.py:262-270)
         tp = min(t - 20, 999)
@@ -280,7 +288,8 @@ def test_step_kernels_bit_exact(ctx):
         x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
         ref = a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * e
         out = torch.empty_like(x, device=DEV)
-        ctx.call("pnpi_ddim_next_step", ptr(e.contiguous().to(DEV)), t, 20, ptr(x.to(DEV)), x.numel(), ptr(out))
+        ed = e.contiguous().to(DEV)
+        ctx.call("pnpi_ddim_next_step", ptr(ed), t, 20, ptr(xd), x.numel(), ptr(out))
         assert torch.equal(out.cpu(), ref), t
         # CFG + prev_step + offset (inversion.py:383-389)
         a_t = ac[t]
@@ -294,13 +303,15 @@ def test_step_kernels_bit_exact(ctx):
         cur = prev + loss
         off = torch.empty(2, 4, 16, 16, device=DEV)
         xo = torch.empty(2, 4, 16, 16, device=DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4.to(DEV)), ptr(x.to(DEV)), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(target.to(DEV)),
+        td = target.to(DEV)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td),
                  ptr(off), ptr(xo))
         assert torch.equal(off.cpu(), loss) and torch.equal(xo.cpu(), cur), t
         # guidance step with noise_loss on the first row only (p2p_guidance_forward.py:110-114)
         nl = torch.randn(2, 4, 16, 16, generator=g)
         ref2 = torch.cat((prev[:1] + nl[:1], prev[1:]))
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4.to(DEV)), ptr(x.to(DEV)), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nl.to(DEV)), 1, None, None,
+        nld = nl.to(DEV)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, None,
                  ptr(xo))
         assert torch.equal(xo.cpu(), ref2), t
 
@@ -311,7 +322,8 @@ def test_local_blend(ctx):
     acc = torch.rand(1, nslots, 2, mhw * mhw, generator=g)
     lat = torch.randn(1, 2, Cc, lhw, lhw, generator=g)
     d_lat = lat.clone().to(DEV)
-    ctx.call("pnpi_op_local_blend", ptr(acc.to(DEV)), nslots, mhw, lhw, Cc, 0.3, ptr(d_lat), 1)
+    accd = acc.to(DEV)
+    ctx.call("pnpi_op_local_blend", ptr(accd), nslots, mhw, lhw, Cc, 0.3, ptr(d_lat), 1)
     # LocalBlend.get_mask / __call__ (attention_control.py:97-121)
     maps = acc[0].permute(1, 0, 2).reshape(2, nslots, 1, mhw, mhw).mean(1)
     m = F.max_pool2d(maps, (3, 3), (1, 1), padding=(1, 1))

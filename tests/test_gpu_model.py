@@ -1,0 +1,107 @@
+"""Whole-graph parity of the native UNet / VAE against the CPU oracle (oracle/sd_oracle.py) on identical seeded weights.
+Stated tolerances (fp16 activations / fp32 accumulation vs fp32 oracle), cf. SURVEY.md 8(d):
+  UNet single forward: rel-L2(eps) <= 4e-3;  VAE encode mean: rel-L2 <= 4e-3;  VAE decode: rel-L2 <= 6e-3, |pixel diff| mean <= 2/255."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sd_oracle  # noqa: E402  (checker only)
+from pnpinversion_amd import weights  # noqa: E402
+from pnpinversion_amd.config import SD1, TINY16, SMALL64  # noqa: E402
+from pnpinversion_amd.engine import NativeEngine  # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _lat(cfg, rows, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(rows, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = TINY16
+    usd, vsd = weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1)
+    eng = NativeEngine(cfg, max_unet_rows=8, max_vae_images=2)
+    eng.load_state_dict(usd, vsd)
+    n, names = eng.missing_weights()
+    assert n == 0, names[:10]
+    yield cfg, usd, vsd, eng
+    eng.close()
+
+
+@pytest.mark.parametrize("rows,t", [(1, 981), (4, 500), (8, 1)])
+def test_unet_tiny(tiny, rows, t):
+    cfg, usd, vsd, eng = tiny
+    lat = _lat(cfg, rows, 5)
+    ctx = weights.synth_context(cfg, rows, seed=7)
+    got = eng.unet(lat, t, ctx, rows_per_image=1)
+    with torch.no_grad():
+        ref = sd_oracle.unet_forward(usd, cfg, lat, t, ctx)
+    assert torch.isfinite(got).all()
+    assert rel(got, ref) < 4e-3, rel(got, ref)
+
+
+def test_vae_tiny(tiny):
+    cfg, usd, vsd, eng = tiny
+    g = torch.Generator().manual_seed(9)
+    f = cfg.vae_scale
+    S = cfg.sample_size * f
+    img = torch.rand(2, 3, S, S, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref_m = sd_oracle.vae_encode_mean(vsd, cfg, img)
+    got_m = eng.vae_encode(img)
+    assert rel(got_m, ref_m) < 4e-3, rel(got_m, ref_m)
+    z = torch.randn(2, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    with torch.no_grad():
+        ref_d = sd_oracle.vae_decode(vsd, cfg, z)
+    got_d = eng.vae_decode(z)
+    assert rel(got_d, ref_d) < 6e-3, rel(got_d, ref_d)
+    # uint8 image paths (utils/utils.py:58-80)
+    u8 = (torch.rand(1, S, S, 3, generator=g) * 255).to(torch.uint8)
+    x = u8[0].float() / 127.5 - 1
+    with torch.no_grad():
+        ref_z = sd_oracle.vae_encode_mean(vsd, cfg, x.permute(2, 0, 1)[None]) * 0.18215
+    got_z = eng.image2latent(u8)
+    assert rel(got_z, ref_z) < 4e-3
+    with torch.no_grad():
+        xr = sd_oracle.vae_decode(vsd, cfg, 1 / 0.18215 * ref_z)
+    ref_img = ((xr / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)
+    got_img = eng.latent2image(ref_z).cpu().numpy()
+    assert np.abs(got_img.astype(np.int32) - ref_img.astype(np.int32)).mean() < 2.0
+
+
+def test_unet_and_vae_sd1_full_width():
+    """Full SD-1.x width (859.5 M-parameter UNet, 83.7 M VAE): one B=1 UNet forward, VAE at 256x256."""
+    cfg = SD1
+    usd = weights.unet_state_dict(cfg, 0)
+    vsd = weights.vae_state_dict(cfg, 0)
+    eng = NativeEngine(cfg, max_unet_rows=4, max_vae_images=1)
+    eng.load_state_dict(usd, vsd)
+    assert eng.missing_weights()[0] == 0
+    lat = _lat(cfg, 1, 11)
+    ctx = weights.synth_context(cfg, 1, seed=12)
+    got = eng.unet(lat, 481, ctx)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = sd_oracle.unet_forward(usd, cfg, lat, 481, ctx)
+    assert rel(got, ref) < 4e-3, rel(got, ref)
+    # B=4 rows must equal 4 independent B=1 evaluations (batch invariance of the native kernels)
+    lat4 = torch.cat([lat, _lat(cfg, 3, 13)])
+    ctx4 = torch.cat([ctx, weights.synth_context(cfg, 3, seed=14)])
+    got4 = eng.unet(lat4, 481, ctx4)
+    assert rel(got4[:1], ref) < 4e-3
+    g = torch.Generator().manual_seed(15)
+    img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref_m = sd_oracle.vae_encode_mean(vsd, cfg, img)
+        z = torch.randn(1, 4, 32, 32, generator=g)
+        ref_d = sd_oracle.vae_decode(vsd, cfg, z)
+    assert rel(eng.vae_encode(img), ref_m) < 4e-3
+    assert rel(eng.vae_decode(z), ref_d) < 6e-3
+    eng.close()
