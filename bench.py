@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- edited images/sec of the direct-inversion + Prompt-to-Prompt hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one complete `P2PEditor("directinversion+p2p", ...)` edit of one 512x512 image per rank, FAITHFUL schedule of the
+reference (models/p2p_editor.py:415-479): VAE encode, the discarded VAE decode, 50 B=1 DDIM-inversion UNet calls, 50 B=4
+offset-calculation calls, 50 B=4 reconstruct-pass calls (AttentionStore), 50 B=4 edit-pass calls (AttentionRefine +
+AttentionReweight + LocalBlend -- the PIE-Bench default controller, run_editing_p2p.py:120-138), 4 more VAE decodes, uint8
+read-back and the 4-panel image: 650 UNet sample-forwards + 1 encode + 5 decodes = 535.9 TFLOP algorithmic.
+Weights are seeded-synthetic SD-1.x (no checkpoint exists offline), input image and prompts are synthetic.
+
+Multi-GPU: images are independent -> each rank edits its own image (weak scaling, no data-path collective); the only
+collective is the start-up RCCL broadcast of the packed weight arena from rank 0 (untimed set-up).
+
+Extra objects in the JSON line:
+  roofline      dominant kernel class (the MFMA implicit-GEMM conv/linear kernel): algorithmic FLOPs / summed per-launch HIP-event
+                durations, measured by bracketing every launch of one full edit with events on the library's stream.
+  cpu_baseline  the CPU oracle (a port of the reference's fp32 PyTorch path, oracle/) timed on this host: one B=1 and one B=4
+                full-width UNet forward + VAE encode + decode, scaled by the faithful schedule's call counts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+UNET_GFLOP = 803.27          # per sample-forward
+VAE_ENC_TFLOP, VAE_DEC_TFLOP = 1.117, 2.515
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16, MI355X_MICROARCH.md
+PROMPT_SRC = "a cat sitting on a wooden chair"
+PROMPT_TGT = "a dog sitting on a wooden chair"
+
+
+def synthetic_image(seed):
+    """Smooth seeded 512x512 RGB uint8 image (the reference's example JPEGs are not on the GPU box)."""
+    g = np.random.Generator(np.random.Philox(key=[seed, 77]))
+    low = g.uniform(0, 255, size=(16, 16, 3)).astype(np.float32)
+    img = np.kron(low, np.ones((32, 32, 1), dtype=np.float32))
+    img += g.normal(0, 6, size=img.shape).astype(np.float32)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def cpu_baseline(cfg, budget_s=40.0):
+    """Oracle (CPU port of the reference's fp32 path) on the host cores: a BOUNDED sample (about 10-30 s of CPU work), scaled to
+    one faithful edit by the schedule's call counts.  Thread count is capped: 200+ threads on these small convolutions is slower
+    than 32."""
+    from oracle import sd_oracle
+    from pnpinversion_amd import weights
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    usd, vsd = weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(4, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    ctx = weights.synth_context(cfg, 4, seed=1)
+    t, start = {}, time.perf_counter()
+    with torch.no_grad():
+        sd_oracle.unet_forward(usd, cfg, lat[:1, :, :16, :16].contiguous(), 500, ctx[:1])      # warm-up (thread pool, allocator)
+        t0 = time.perf_counter(); sd_oracle.unet_forward(usd, cfg, lat[:1], 500, ctx[:1]); t["unet_b1"] = time.perf_counter() - t0
+        if time.perf_counter() - start + 4 * t["unet_b1"] < budget_s:
+            t0 = time.perf_counter(); sd_oracle.unet_forward(usd, cfg, lat, 500, ctx); t["unet_b4"] = time.perf_counter() - t0
+            b4_note = "1x UNet B=4 (%.2fs)" % t["unet_b4"]
+        else:
+            t["unet_b4"] = 4 * t["unet_b1"]
+            b4_note = "UNet B=4 taken as 4x B=1"
+        # VAE at 256x256 (1/4 of the pixels), scaled x4: conv cost is linear in pixels
+        img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+        t0 = time.perf_counter(); sd_oracle.vae_encode_mean(vsd, cfg, img); t["vae_enc"] = 4 * (time.perf_counter() - t0)
+        t0 = time.perf_counter(); sd_oracle.vae_decode(vsd, cfg, lat[:1, :, :32, :32].contiguous()); t["vae_dec"] = 4 * (time.perf_counter() - t0)
+    per_image = 50 * t["unet_b1"] + 150 * t["unet_b4"] + t["vae_enc"] + 5 * t["vae_dec"]
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "oracle fp32, %d threads: 1x UNet B=1 (%.2fs), %s, VAE enc+dec at 256^2 x4 (%.2fs, %.2fs); scaled x(50, 150, 1, 5) "
+                      "= %.0f s/image; sample wall %.0fs" % (threads, t["unet_b1"], b4_note, t["vae_enc"], t["vae_dec"], per_image,
+                                                             time.perf_counter() - start)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pnpinversion_amd.config import SD1
+    from pnpinversion_amd.distributed import broadcast_weights
+    from pnpinversion_amd.p2p_editor import P2PEditor
+    from pnpinversion_amd.pipeline import NativePipeline
+    from pnpinversion_amd import weights
+
+    cfg = SD1
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=4, max_vae_images=2)
+    if rank == 0:
+        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0))
+    if world > 1:
+        broadcast_weights(pipe.engine, src=0)       # the one collective: RCCL broadcast of the packed arena over xGMI
+    editor = P2PEditor(["directinversion+p2p"], "cuda:%d" % local_rank, num_ddim_steps=args.ddim_steps, pipeline=pipe)
+    eng = pipe.engine
+
+    def one_edit(i):
+        img = synthetic_image(1000 * rank + i)
+        return editor("directinversion+p2p", image_path=img, prompt_src=PROMPT_SRC, prompt_tar=PROMPT_TGT, guidance_scale=7.5,
+                      cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=(("cat",), ("dog",)),
+                      eq_params={"words": ("dog",), "values": (2,)})
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_edit(i)
+    barrier()
+    eng.reset_counters()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        panel = one_edit(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ctr = eng.counters()
+    assert panel.size == (2048, 512)
+
+    # per-kernel-class roofline: one more full edit with every launch bracketed by HIP events (rank 0, outside the timed region)
+    roofline, classes = None, None
+    if rank == 0:
+        eng.profile_begin()
+        one_edit(999)
+        classes = eng.profile_end()
+        gemm = {k: classes[k] for k in ("igemm128", "igemm64", "igemm64_splitk")}
+        dom = max(gemm, key=lambda k: gemm[k]["total_ms"])
+        tot_ms = sum(v["total_ms"] for v in gemm.values())
+        tot_fl = sum(v["flops"] for v in gemm.values())
+        ach = gemm[dom]["flops"] / (gemm[dom]["total_ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel (%s)" % dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches": gemm[dom]["launches"], "avg_launch_us": gemm[dom]["total_ms"] * 1e3 / max(1, gemm[dom]["launches"]),
+                    "all_igemm_achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                    "classes": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
+                                    "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["total_ms"] > 0 and v["flops"] > 0 else None,
+                                    "GBps": (v["bytes"] / (v["total_ms"] * 1e-3) / 1e9) if v["total_ms"] > 0 and v["bytes"] > 0 else None}
+                                for k, v in classes.items()}}
+
+    if rank == 0:
+        n_img = args.steps * world
+        per_rank_flops = (ctr["unet_sample_forwards"] * UNET_GFLOP * 1e9 + ctr["vae_encodes"] * VAE_ENC_TFLOP * 1e12 +
+                          ctr["vae_decodes"] * VAE_DEC_TFLOP * 1e12)
+        out = {
+            "metric": "edited images/sec @ 512x512, 50 DDIM-inv + 50 denoise steps",
+            "value": n_img / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (fp32 accumulate; latents / scheduler math fp32)", "data": "synthetic",
+            "config": {"workload": "single 512x512 image per rank, SD-1.x (seeded synthetic weights), directinversion+p2p, "
+                                   "faithful schedule: 650 UNet sample-forwards + 1 VAE encode + 5 VAE decodes per image, "
+                                   "Refine+Reweight+LocalBlend controller",
+                       "ddim_steps": args.ddim_steps, "images_per_step_per_gpu": 1,
+                       "unet_sample_forwards_per_image": ctr["unet_sample_forwards"] / max(1, args.steps),
+                       "algorithmic_tflop_per_image": per_rank_flops / max(1, args.steps) / 1e12},
+            "whole_path_tflops_per_gpu": per_rank_flops / dt / 1e12,
+            "whole_path_mfma_frac": per_rank_flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

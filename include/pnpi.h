@@ -112,6 +112,19 @@ int pnpi_set_scheduler(pnpi_ctx* ctx, const float* alphas_cumprod_host, int n_tr
 int pnpi_get_counters(const pnpi_ctx* ctx, pnpi_counters* out);
 int pnpi_reset_counters(pnpi_ctx* ctx);
 
+/* Per-kernel-class timing with HIP events on the ctx stream (used by bench.py for the `roofline` object).
+ * Between begin and end every kernel launch of the graph executor is bracketed by two events. */
+enum { PNPI_KC_IGEMM128 = 0, PNPI_KC_IGEMM64 = 1, PNPI_KC_IGEMM64_SPLITK = 2, PNPI_KC_ATTN_FLASH = 3, PNPI_KC_ATTN_EDIT = 4,
+       PNPI_KC_GROUPNORM = 5, PNPI_KC_LAYERNORM = 6, PNPI_KC_GEGLU = 7, PNPI_KC_SOFTMAX = 8, PNPI_KC_COUNT = 9 };
+typedef struct {
+  uint64_t launches;
+  double total_ms;      /* sum of per-launch durations */
+  double flops;         /* algorithmic FLOPs (2*M*N*K of the logical problem, head padding excluded for attention) */
+  double bytes;         /* algorithmic HBM bytes for the bandwidth-bound classes */
+} pnpi_kernel_stats;
+int pnpi_profile_begin(pnpi_ctx* ctx);
+int pnpi_profile_end(pnpi_ctx* ctx, pnpi_kernel_stats* out /* [PNPI_KC_COUNT] */);
+
 /* ---- level 1: operator boundary (keeps the loops under models/p2p/ usable unmodified) ---------------------------- */
 /* model.unet(latents, t, encoder_hidden_states=context)["sample"]    inversion.py:273, p2p_guidance_forward.py:109 */
 int pnpi_unet_forward(pnpi_ctx* ctx, const float* latents, int rows, int rows_per_image, int t, const float* context,

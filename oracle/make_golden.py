@@ -1,0 +1,165 @@
+"""Generate tests/golden/* by running the REFERENCE's own code (imported from /root/reference through oracle/ref_shim.py) on
+CPU with the seeded synthetic weights.  Run in the build container only:   python -m oracle.make_golden
+
+Fixtures (the reference has no tests / golden vectors of its own for this path -- SURVEY.md 8c -- so these pin the oracle):
+  host_tables.json     get_word_inds / refinement + replacement mappers / alpha schedule / equalizer / LocalBlend selectors
+  unet_tiny.npz        my_diffusers UNet2DConditionModel + the reference's hooked attention, TINY16, B=4
+  vae_tiny.npz         my_diffusers AutoencoderKL encode mean / decode, TINY16
+  unet_sd1.npz         full-width SD-1.x UNet, B=1
+  vae_sd1.npz          full-width SD-1.x VAE encode (256x256) / decode (16x16 latent)
+  e2e_refine.npz       models/p2p_editor.py P2PEditor("directinversion+p2p") stage outputs, SMALL64, 2+2 steps,
+                       AttentionRefine + AttentionReweight + LocalBlend (the PIE-Bench default controller)
+  e2e_replace.npz      same with is_replace_controller=True (AttentionReplace), no blend / reweight
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from pnpinversion_amd import weights  # noqa: E402
+from pnpinversion_amd.config import SD1, SMALL64, TINY16  # noqa: E402
+from pnpinversion_amd.text import SyntheticTextEncoder, WordTokenizer  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+PROMPT_PAIRS = [
+    ("a cat sitting on a wooden chair", "a dog sitting on a wooden chair", "cat", "dog"),
+    ("a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate", "cake", "cake"),
+    ("a photograph of a mountain", "a watercolor photograph of a snowy mountain", "mountain", "mountain"),
+    ("an elephant walking", "a strawberry elephant walking slowly", "elephant", "elephant"),
+]
+
+
+def host_tables():
+    ref_shim.install()
+    from models.p2p import seq_aligner
+    from models.p2p.attention_control import LocalBlend, get_equalizer
+    from utils.utils import get_time_words_attention_alpha, get_word_inds
+    tok = WordTokenizer()
+    out = []
+    for (src, tgt, w0, w1) in PROMPT_PAIRS:
+        e = {"src": src, "tgt": tgt, "blend": [w0, w1]}
+        e["word_inds_src"] = get_word_inds(src, w0, tok).tolist()
+        e["word_inds_tgt"] = get_word_inds(tgt, w1, tok).tolist()
+        e["word_inds_int"] = get_word_inds(tgt, 1, tok).tolist()
+        m, a = seq_aligner.get_refinement_mapper([src, tgt], tok)
+        e["refine_mapper"] = m[0].tolist()
+        e["refine_alphas"] = a[0].tolist()
+        if len(src.split(" ")) == len(tgt.split(" ")):
+            e["replace_mapper"] = seq_aligner.get_replacement_mapper([src, tgt], tok)[0].tolist()
+        for steps in (50, 2):
+            al = get_time_words_attention_alpha([src, tgt], steps, {"default_": 0.4}, tok)
+            e["cross_alpha_%d" % steps] = al.reshape(steps + 1, 77).tolist()
+        e["equalizer"] = get_equalizer(tgt, (w1,), (2,), tokenizer=tok)[0].tolist()
+        with ref_shim.cuda_to_cpu():
+            lb = LocalBlend([src, tgt], ((w0,), (w1,)), tokenizer=tok, device="cpu", num_ddim_steps=50)
+        e["lb_alpha"] = lb.alpha_layers.reshape(2, 77).tolist()
+        e["lb_start"] = lb.start_blend
+        out.append(e)
+    json.dump(out, open(os.path.join(OUT, "host_tables.json"), "w"))
+    print("host_tables.json", len(out))
+
+
+def model_goldens():
+    ref_shim.install()
+    from models.p2p.attention_control import register_attention_control
+    for name, cfg, rows, t, seed in (("tiny", TINY16, 4, 500, 1), ("sd1", SD1, 1, 481, 0)):
+        t0 = time.time()
+        usd, vsd = weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed)
+        g = torch.Generator().manual_seed(100 + seed)
+        lat = torch.randn(rows, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g)
+        ctx = weights.synth_context(cfg, rows, seed=200 + seed)
+        unet = ref_shim.build_unet(cfg, usd)
+        h = ref_shim._Holder()
+        h.unet = unet
+        register_attention_control(h, None)          # the reference's hooked attention forward with its DummyController
+        with torch.no_grad():
+            eps = unet(lat, torch.tensor(t), encoder_hidden_states=ctx)["sample"]
+        np.savez_compressed(os.path.join(OUT, "unet_%s.npz" % name), latents=lat.numpy(), context=ctx.numpy().astype(np.float16),
+                            t=np.int64(t), seed=np.int64(seed), eps=eps.numpy())
+        del unet
+        vae = ref_shim.build_vae(cfg, vsd)
+        S = 64 if name == "tiny" else 256
+        img = (torch.rand(1, 3, S, S, generator=g) * 2 - 1).half().float()   # fp16-representable (stored as fp16)
+        zs = 8 if name == "tiny" else 16
+        z = torch.randn(1, 4, zs, zs, generator=g)
+        with torch.no_grad():
+            mean = vae.encode(img)["latent_dist"].mean
+            dec = vae.decode(z)["sample"]
+        np.savez_compressed(os.path.join(OUT, "vae_%s.npz" % name), image=img.numpy().astype(np.float16), z=z.numpy(),
+                            mean=mean.numpy(), dec=dec.numpy(), seed=np.int64(seed))
+        del vae
+        print("model goldens", name, "%.1fs" % (time.time() - t0))
+
+
+def e2e(name, is_replace, blend, steps=2):
+    ref_shim.install()
+    cfg = SMALL64
+    t0 = time.time()
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    tok = WordTokenizer()
+    enc = SyntheticTextEncoder(cfg.cross_dim, seed=7)
+    ed = ref_shim.build_editor(cfg, usd, vsd, tok, enc, steps)
+    src, tgt, w0, w1 = PROMPT_PAIRS[1] if is_replace else PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    stages = {}
+    import models.p2p_editor as pe
+    import models.p2p.inversion as inv
+    orig_invert = inv.DirectInversion.invert
+
+    def invert_spy(self, *a, **k):
+        r = orig_invert(self, *a, **k)
+        stages["x_stars"] = torch.stack([x.clone() for x in r[2]]).numpy()
+        stages["noise_loss"] = torch.stack([x.clone() for x in r[3]]).numpy()
+        stages["context"] = self.context.clone().numpy()
+        return r
+
+    orig_fwd = pe.direct_inversion_p2p_guidance_forward
+    calls = []
+
+    def fwd_spy(*a, **k):
+        r = orig_fwd(*a, **k)
+        calls.append(r[0].clone().numpy())
+        return r
+
+    inv.DirectInversion.invert = invert_spy
+    pe.direct_inversion_p2p_guidance_forward = fwd_spy
+    try:
+        with ref_shim.cuda_to_cpu(), torch.no_grad():
+            panel = ed("directinversion+p2p", image_path=img, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5,
+                       cross_replace_steps=0.4, self_replace_steps=0.6,
+                       blend_word=((w0,), (w1,)) if blend else None,
+                       eq_params={"words": (w1,), "values": (2,)} if blend else None,
+                       is_replace_controller=is_replace)
+    finally:
+        inv.DirectInversion.invert = orig_invert
+        pe.direct_inversion_p2p_guidance_forward = orig_fwd
+    panel = np.array(panel)
+    S = 512
+    np.savez_compressed(os.path.join(OUT, "e2e_%s.npz" % name), x_stars=stages["x_stars"], noise_loss=stages["noise_loss"],
+                        context=stages["context"].astype(np.float16), reconstruct_latent=calls[0], edited_latents=calls[1],
+                        recon_image_small=panel[::4, 2 * S:3 * S:4], edited_image_small=panel[::4, 3 * S::4],
+                        src=src, tgt=tgt, blend=np.array([w0, w1]), steps=np.int64(steps), is_replace=np.bool_(is_replace),
+                        use_blend=np.bool_(blend))
+    print("e2e", name, "%.1fs" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    which = sys.argv[1:] or ["host", "models", "e2e"]
+    if "host" in which:
+        host_tables()
+    if "models" in which:
+        model_goldens()
+    if "e2e" in which:
+        e2e("refine", False, True)
+        e2e("replace", True, False)

@@ -40,6 +40,13 @@ class Counters(C.Structure):
                 ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double)]
 
 
+KC_NAMES = ["igemm128", "igemm64", "igemm64_splitk", "attn_flash", "attn_cross_edit", "groupnorm", "layernorm", "geglu", "softmax"]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 # every symbol include/pnpi.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ip = C.POINTER(C.c_int)
@@ -55,6 +62,8 @@ SYMBOLS = {
     "pnpi_set_scheduler": (_i, [_vp, C.POINTER(C.c_float), _i, _f]),
     "pnpi_get_counters": (_i, [_vp, C.POINTER(Counters)]),
     "pnpi_reset_counters": (_i, [_vp]),
+    "pnpi_profile_begin": (_i, [_vp]),
+    "pnpi_profile_end": (_i, [_vp, C.POINTER(KernelStats)]),
     "pnpi_unet_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(CtrlDesc), _i, _vp]),
     "pnpi_local_blend": (_i, [_vp, _vp, _i, _i]),
     "pnpi_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _vp]),

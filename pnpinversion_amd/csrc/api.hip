@@ -257,6 +257,29 @@ static void build_model(pnpi_ctx* c) {
   v.d_conv_out = make_conv(c, "vae.decoder.conv_out", vb[0], g.vae_in_channels, 3);
 }
 
+// ---------------------------------------------------------------------------------------------------- profiling
+static void prof_open(pnpi_ctx* c, ProfRec& r) {
+  (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+  (void)hipEventRecord(r.a, c->st);
+}
+static void prof_close(pnpi_ctx* c, ProfRec& r, int cls, double flops, double bytes) {
+  (void)hipEventRecord(r.b, c->st);
+  r.cls = cls; r.flops = flops; r.bytes = bytes;
+  c->prof.push_back(r);
+}
+#define PROF(cls, flops, bytes, expr)                         \
+  do {                                                        \
+    if (c->prof_on && !c->dry) {                              \
+      ProfRec _pr; prof_open(c, _pr);                         \
+      int _r = (expr);                                        \
+      prof_close(c, _pr, (cls), (flops), (bytes));            \
+      if (_r) return fail_launch(c, _r, #expr);               \
+    } else {                                                  \
+      int _r = (expr);                                        \
+      if (_r) return fail_launch(c, _r, #expr);               \
+    }                                                         \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------------- op wrappers
 static half_t* talloc(pnpi_ctx* c, size_t n) { return (half_t*)c->temp.alloc(n * sizeof(half_t)); }
 static half_t* palloc(pnpi_ctx* c, size_t n) { return (half_t*)c->persist.alloc(n * sizeof(half_t)); }
@@ -264,10 +287,23 @@ static half_t* palloc(pnpi_ctx* c, size_t n) { return (half_t*)c->persist.alloc(
 static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, const NormW& nw, int G, float eps,
                  int silu, half_t* out) {
   if (c->dry) return 0;
-  return launch_groupnorm(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, c->gn_partial, c->st);
+  PROF(PNPI_KC_GROUPNORM, 0.0, 3.0 * B * HW * (double)(C1 + C2) * 2.0,
+       launch_groupnorm(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, c->gn_partial, c->st));
+  return 0;
 }
 
 struct VtOut { void* outT = nullptr; int col0 = 1 << 30; int ld = 0; int f32 = 0; int rpb = 1; };
+
+static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops) {
+  if (c->prof_on) {
+    ProfRec pr; prof_open(c, pr);
+    int used = 0;
+    int r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, &used);
+    prof_close(c, pr, used, alg_flops, 0.0);
+    return r;
+  }
+  return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
+}
 
 static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int C2, int B, int H, int W, const ConvW& w, int stride,
                    int pad, int ups, const float* bias, const half_t* res, half_t* out, int Ho, int Wo, int N = -1,
@@ -282,11 +318,12 @@ static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int 
   if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
   c->ctr.executed_gemm_flops += 2.0 * p.M * p.N * p.K;
   if (c->dry) return 0;
-  return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
+  return igemm_prof(c, p, 2.0 * p.M * (double)w.cout * w.k * w.k * w.cin);
 }
 
 static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const half_t* w, int ldw, int N, const float* bias,
-                   const half_t* res, int ldres, half_t* out, int ldo, float alpha = 1.f, const VtOut* vt = nullptr) {
+                   const half_t* res, int ldres, half_t* out, int ldo, float alpha = 1.f, const VtOut* vt = nullptr,
+                   double alg_flops = -1.0) {
   GemmP p; gemm_defaults(p);
   p.x1 = a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
   p.w = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = res; p.ldres = ldres; p.alpha = alpha;
@@ -294,7 +331,7 @@ static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const ha
   if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
   c->ctr.executed_gemm_flops += 2.0 * M * N * K;
   if (c->dry) return 0;
-  return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
+  return igemm_prof(c, p, alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K);
 }
 
 // ResnetBlock2D.forward (my_diffusers/models/resnet.py:331-365); x2 = skip tensor concatenated on the channel axis
@@ -339,13 +376,13 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
 
   // ---- self-attention
   half_t* n1 = talloc(c, (size_t)M * C);
-  if (!c->dry) CK(launch_layernorm(hs, M, C, 1e-5f, t.ln1.g, t.ln1.b, n1, c->st));
+  if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)C * 2.0, launch_layernorm(hs, M, C, 1e-5f, t.ln1.g, t.ln1.b, n1, c->st));
   half_t* qk = talloc(c, (size_t)M * 2 * hd);
   const int ldv = round_up_i(N, 8);
   half_t* vt = talloc(c, (size_t)B * hd * ldv);
   {
     VtOut v; v.outT = vt; v.col0 = 2 * hd; v.ld = ldv; v.f32 = 0; v.rpb = N;
-    CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qk, 2 * hd, 1.f, &v));
+    CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qk, 2 * hd, 1.f, &v, 2.0 * M * 3.0 * C * C));
   }
   half_t* ao = talloc(c, (size_t)M * C);
   {
@@ -354,22 +391,22 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
     a.rows = rep ? cd.rows_rep : cd.rows_id; a.nrows = B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
-    if (!c->dry) CK(launch_attn_flash(a, c->st));
+    if (!c->dry) PROF(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, launch_attn_flash(a, c->st));
   }
   half_t* hs1 = talloc(c, (size_t)M * C);
   CK(op_gemm(c, ao, C, M, C, t.o1.w, C, C, t.o1.b, hs, C, hs1, C));
 
   // ---- cross-attention
   half_t* n2 = talloc(c, (size_t)M * C);
-  if (!c->dry) CK(launch_layernorm(hs1, M, C, 1e-5f, t.ln2.g, t.ln2.b, n2, c->st));
+  if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)C * 2.0, launch_layernorm(hs1, M, C, 1e-5f, t.ln2.g, t.ln2.b, n2, c->st));
   half_t* q2 = talloc(c, (size_t)M * hd);
-  CK(op_gemm(c, n2, C, M, C, t.w_q2, C, hd, nullptr, nullptr, 0, q2, hd));
+  CK(op_gemm(c, n2, C, M, C, t.w_q2, C, hd, nullptr, nullptr, 0, q2, hd, 1.f, nullptr, 2.0 * M * (double)C * C));
   half_t* k2 = talloc(c, (size_t)B * T * hd);
   const int ldv2 = round_up_i(T, 8);
   half_t* vt2 = talloc(c, (size_t)B * hd * ldv2);
   {
     VtOut v; v.outT = vt2; v.col0 = hd; v.ld = ldv2; v.f32 = 0; v.rpb = T;
-    CK(op_gemm(c, ctx16, X, B * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v));
+    CK(op_gemm(c, ctx16, X, B * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v, 2.0 * B * T * 2.0 * C * X));
   }
   half_t* ao2 = talloc(c, (size_t)M * C);
   {
@@ -377,7 +414,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     a.rows = edit ? cd.rows_plain : cd.rows_id; a.nrows = edit ? cd.n_plain : B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * 96 * t.Dp;
-    if (!c->dry) CK(launch_attn_flash(a, c->st));
+    if (!c->dry) PROF(PNPI_KC_ATTN_FLASH, 4.0 * a.nrows * t.heads * (double)N * T * t.dh, 0.0, launch_attn_flash(a, c->st));
     if (edit && !c->dry) {
       CrossEditP e; e.q = q2; e.ldq = hd; e.q_off = 0; e.k = k2; e.ldk = hd; e.k_off = 0; e.vt = vt2; e.ldv = ldv2;
       e.o = ao2; e.ldo = C; e.heads = t.heads; e.Nq = N; e.Nk = T; e.Dp = t.Dp; e.dh = t.dh; e.scale = scale;
@@ -389,7 +426,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
       e.lb_alpha = lb ? cd.lb_alpha : nullptr;
       e.lb_acc = lb ? cd.lb_acc : nullptr;
       e.lb_slot0 = t.lb_slot0; e.lb_nslots = c->unet.lb_nslots;
-      CK(launch_attn_cross_edit(e, c->st));
+      PROF(PNPI_KC_ATTN_EDIT, 4.0 * 2 * cd.npairs * t.heads * (double)N * T * t.dh, 0.0, launch_attn_cross_edit(e, c->st));
     }
   }
   half_t* hs2 = talloc(c, (size_t)M * C);
@@ -397,11 +434,11 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
 
   // ---- GEGLU feed-forward
   half_t* n3 = talloc(c, (size_t)M * C);
-  if (!c->dry) CK(launch_layernorm(hs2, M, C, 1e-5f, t.ln3.g, t.ln3.b, n3, c->st));
+  if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)C * 2.0, launch_layernorm(hs2, M, C, 1e-5f, t.ln3.g, t.ln3.b, n3, c->st));
   half_t* f1 = talloc(c, (size_t)M * 8 * C);
   CK(op_gemm(c, n3, C, M, C, t.ff1.w, C, 8 * C, t.ff1.b, nullptr, 0, f1, 8 * C));
   half_t* f2 = talloc(c, (size_t)M * 4 * C);
-  if (!c->dry) CK(launch_geglu(f1, M, 4 * C, f2, c->st));
+  if (!c->dry) PROF(PNPI_KC_GEGLU, 0.0, 12.0 * M * (double)C * 2.0, launch_geglu(f1, M, 4 * C, f2, c->st));
   half_t* hs3 = talloc(c, (size_t)M * C);
   CK(op_gemm(c, f2, 4 * C, M, 4 * C, t.ff2.w, 4 * C, C, t.ff2.b, hs2, C, hs3, C));
   CK(op_conv(c, hs3, C, nullptr, 0, B, H, W, t.proj_out, 1, 0, 0, t.proj_out.b, x, out, H, W));
@@ -517,7 +554,7 @@ static int vae_attn_fwd(pnpi_ctx* c, const VaeAttnW& a, const half_t* x, int B, 
   for (int b = 0; b < B; ++b) {
     const half_t* qb = qk + (size_t)b * N * 2 * C;
     CK(op_gemm(c, qb, 2 * C, N, C, qb + C, 2 * C, N, nullptr, nullptr, 0, sc, ldv, alpha));
-    if (!c->dry) CK(launch_softmax_rows(sc, N, N, ldv, c->st));
+    if (!c->dry) PROF(PNPI_KC_SOFTMAX, 0.0, 2.0 * N * (double)N * 2.0, launch_softmax_rows(sc, N, N, ldv, c->st));
     CK(op_gemm(c, sc, ldv, N, N, vt + (size_t)b * C * ldv, ldv, C, nullptr, nullptr, 0, ao + (size_t)b * N * C, C));
   }
   CK(op_gemm(c, ao, C, M, C, a.proj.w, C, C, a.proj.b, x, C, out, C));
@@ -911,6 +948,30 @@ int pnpi_set_scheduler(pnpi_ctx* c, const float* ac, int n_train, float final_al
 
 int pnpi_get_counters(const pnpi_ctx* c, pnpi_counters* out) { if (!c || !out) return PNPI_EINVAL; *out = c->ctr; return 0; }
 int pnpi_reset_counters(pnpi_ctx* c) { if (!c) return PNPI_EINVAL; memset(&c->ctr, 0, sizeof(c->ctr)); return 0; }
+
+int pnpi_profile_begin(pnpi_ctx* c) {
+  if (!c) return PNPI_EINVAL;
+  CKH(hipStreamSynchronize(c->st));
+  c->prof.clear();
+  c->prof_on = true;
+  return 0;
+}
+int pnpi_profile_end(pnpi_ctx* c, pnpi_kernel_stats* out) {
+  if (!c || !out) return PNPI_EINVAL;
+  c->prof_on = false;
+  CKH(hipStreamSynchronize(c->st));
+  memset(out, 0, sizeof(pnpi_kernel_stats) * PNPI_KC_COUNT);
+  for (ProfRec& r : c->prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    if (r.cls >= 0 && r.cls < PNPI_KC_COUNT) {
+      out[r.cls].launches += 1; out[r.cls].total_ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes;
+    }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  c->prof.clear();
+  return 0;
+}
 
 static int check_ready(pnpi_ctx* c) {
   for (auto& kv : c->slots) if (!kv.second.loaded) { c->err = "weights not loaded: " + kv.first; return PNPI_ESTATE; }

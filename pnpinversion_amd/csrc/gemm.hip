@@ -224,7 +224,7 @@ int igemm_init() {
   return 0;
 }
 
-int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split) {
+int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -2;
   const int Cin = p.C1 + p.C2;
   if ((Cin & 7) || (p.K & 7) || (p.C1 & 7) || (p.ldw & 7) || (p.ldx1 & 7) || (p.C2 && (p.ldx2 & 7))) return -3;
@@ -250,6 +250,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     size_t need = (size_t)split * p.M * p.N * sizeof(float);
     if (split > 1 && (ws == nullptr || need > ws_bytes)) split = 1;
   }
+  if (cfg_used) *cfg_used = cfg == 0 ? 0 : (split > 1 ? 2 : 1);
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   p.slab = ws;

@@ -132,6 +132,8 @@ struct CtrlDev {
   float* lb_acc = nullptr;        // [npairs][nslots][2][tokens]
 };
 
+struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
+
 struct pnpi_ctx {
   pnpi_model_config cfg;
   int device;
@@ -155,4 +157,6 @@ struct pnpi_ctx {
   pnpi_counters ctr;
   CtrlDev cd;
   std::vector<char> host_stage;
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
 };

@@ -26,7 +26,8 @@ struct GemmP {
 };
 void gemm_defaults(GemmP& p);
 // ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.
-int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0);
+int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0,
+                 int* cfg_used = nullptr);
 int igemm_init();  // sets dynamic-LDS attributes once
 
 // ---------------------------------------------------------------------------------------------------------------

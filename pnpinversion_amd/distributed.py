@@ -1,0 +1,37 @@
+"""Multi-GPU plumbing: one process per GPU (torchrun-style env), torch.distributed backend "nccl" (= RCCL on ROCm, xGMI).
+
+The hot path shards embarrassingly (one image = one independent unit): rank r takes items r, r + W, ...; the only
+collective is one broadcast of the packed weight arena at start-up, so that only rank 0 has to read / generate weights."""
+import os
+
+import torch
+
+
+class _DevView:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def arena_tensor(engine):
+    """uint8 CUDA tensor aliasing the engine's packed weight arena (no copy)."""
+    ptr, nbytes = engine.weight_arena()
+    return torch.as_tensor(_DevView(ptr, nbytes), device=engine.device)
+
+
+def broadcast_weights(engine, src=0, group=None):
+    """RCCL broadcast of the whole arena from `src`; receivers mark their slots loaded."""
+    import torch.distributed as dist
+    t = arena_tensor(engine)
+    torch.cuda.synchronize(engine.device)
+    dist.broadcast(t, src=src, group=group)
+    torch.cuda.synchronize(engine.device)
+    if dist.get_rank(group) != src:
+        engine.mark_all_loaded()
+    return t.numel()
+
+
+def shard_items(items, rank=None, world=None):
+    """Static round-robin partition of an ordered work list (run_editing_p2p.py:102-105 iterates it sequentially)."""
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    return [it for i, it in enumerate(items) if i % world == rank]

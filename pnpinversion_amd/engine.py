@@ -165,6 +165,15 @@ class NativeEngine:
     def reset_counters(self):
         self._call("pnpi_reset_counters")
 
+    def profile_begin(self):
+        self._call("pnpi_profile_begin")
+
+    def profile_end(self):
+        arr = (_capi.KernelStats * len(_capi.KC_NAMES))()
+        self._call("pnpi_profile_end", arr)
+        return {n: dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes)
+                for i, n in enumerate(_capi.KC_NAMES)}
+
     # ---- level 1
     def unet(self, latents, t, context, rows_per_image=1, ctrls=None, cur_step=0):
         lat, ctx = self._f32(latents), self._f32(context)

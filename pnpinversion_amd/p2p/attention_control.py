@@ -1,0 +1,192 @@
+"""Prompt-to-Prompt controllers, declarative form.
+
+Same class names, constructor arguments and error behaviour as the reference's models/p2p/attention_control.py, but instead
+of being called back on a materialised [B*8, N, M] probability tensor at each of the 32 attention sites
+(attention_control.py:44,178-190) a controller here only *describes* the edit: `tables()` returns the host tables that the
+fused HIP attention kernels consume (include/pnpi.h, pnpi_ctrl_desc):
+
+    P_tgt' = c1 * (P_src @ mapper) + c2 * P_tgt,   c1 = a_t * eq * alphas,   c2 = a_t * eq * (1 - alphas) + (1 - a_t)
+
+  AttentionReplace (:301-314)  mapper = replacement mapper [77,77], alphas = 1
+  AttentionRefine  (:317-335)  mapper = one-hot gather of mapper[j] (index -1 selects the last column, weight alphas[j] = 0)
+  AttentionReweight(:338-363)  eq = equalizer, chained after the previous controller's mapper / alphas
+  LocalBlend       (:95-147)   lb_alpha = alpha_layers one-hot rows, start_blend, threshold
+  self-attention replacement window num_self_replace (:295-297) and the <= 32^2-token rule (:258-263)
+"""
+import abc
+
+import numpy as np
+import torch
+
+from ..engine import ControllerTables
+from ..utils.utils import get_time_words_attention_alpha, get_word_inds
+from . import token_align as seq_aligner
+
+MAX_NUM_WORDS = 77
+LATENT_SIZE = (64, 64)
+LOW_RESOURCE = False
+
+
+def get_equalizer(text, word_select, values, tokenizer=None):
+    """attention_control.py:84-92"""
+    if type(word_select) is int or type(word_select) is str:
+        word_select = (word_select,)
+    equalizer = torch.ones(1, 77)
+    for word, val in zip(word_select, values):
+        inds = get_word_inds(text, word, tokenizer)
+        equalizer[:, inds] = val
+    return equalizer
+
+
+class LocalBlend:
+    """Holds the LocalBlend parameters (attention_control.py:123-147); the blend itself runs in the local_blend HIP kernel
+    on the maps accumulated by the cross-attention kernel."""
+
+    def __init__(self, prompts, words, substruct_words=None, start_blend=0.2, th=(.3, .3), tokenizer=None, device="cuda",
+                 num_ddim_steps=50):
+        if substruct_words is not None:
+            raise NotImplementedError("substruct_words is not used by any shipped script and is not implemented natively")
+        alpha_layers = torch.zeros(len(prompts), 1, 1, 1, 1, MAX_NUM_WORDS)
+        for i, (prompt, words_) in enumerate(zip(prompts, words)):
+            if type(words_) is str:
+                words_ = [words_]
+            for word in words_:
+                ind = get_word_inds(prompt, word, tokenizer)
+                alpha_layers[i, :, :, :, :, ind] = 1
+        self.alpha_layers = alpha_layers
+        self.substruct_layers = None
+        self.start_blend = int(start_blend * num_ddim_steps)
+        self.counter = 0
+        self.th = th
+
+
+class EmptyControl:
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    def tables(self):
+        return None
+
+
+class AttentionControl(abc.ABC):
+    def __init__(self):
+        self.cur_step = 0
+        self.num_att_layers = -1
+        self.cur_att_layer = 0
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    def tables(self):
+        return None
+
+
+class AttentionStore(AttentionControl):
+    """AttentionStore (attention_control.py:214-248) has no effect on the denoised latents; natively it is a plain forward.
+    (The only stored maps ever consumed are LocalBlend's five 16x16 cross maps, which the edit kernel accumulates itself.)"""
+
+
+class AttentionControlEdit(AttentionStore, abc.ABC):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer=None, device="cuda"):
+        super().__init__()
+        if len(prompts) != 2:
+            raise NotImplementedError("the native controllers handle one (source, target) prompt pair per image")
+        self.batch_size = len(prompts)
+        self.cross_replace_alpha = get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer)
+        if type(self_replace_steps) is float:
+            self_replace_steps = 0, self_replace_steps
+        self.num_self_replace = int(num_steps * self_replace_steps[0]), int(num_steps * self_replace_steps[1])
+        self.local_blend = local_blend
+        self.num_steps = num_steps
+
+    # host tables ------------------------------------------------------------------------------------------------------
+    def _mapper_alphas(self):
+        raise NotImplementedError
+
+    def _equalizer(self):
+        return np.ones(MAX_NUM_WORDS, dtype=np.float32)
+
+    def tables(self):
+        mapper, alphas = self._mapper_alphas()
+        lb = self.local_blend
+        return ControllerTables(
+            cross_alpha=self.cross_replace_alpha.reshape(self.num_steps + 1, MAX_NUM_WORDS).numpy(),
+            mapper=mapper, alphas=alphas, equalizer=self._equalizer(), self_range=self.num_self_replace,
+            lb_alpha=lb.alpha_layers.reshape(2, MAX_NUM_WORDS).numpy() if lb is not None else None,
+            lb_start=lb.start_blend if lb is not None else 0, lb_threshold=lb.th[0] if lb is not None else 0.3)
+
+
+class AttentionReplace(AttentionControlEdit):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend=None, tokenizer=None, device="cuda"):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer, device)
+        self.mapper = seq_aligner.get_replacement_mapper(prompts, tokenizer)     # [1, 77, 77], raises ValueError on word-count mismatch
+
+    def _mapper_alphas(self):
+        return self.mapper[0].numpy(), np.ones(MAX_NUM_WORDS, dtype=np.float32)
+
+
+class AttentionRefine(AttentionControlEdit):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend=None, tokenizer=None, device="cuda"):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer, device)
+        self.mapper, alphas = seq_aligner.get_refinement_mapper(prompts, tokenizer)   # [1, 77] int64, [1, 77]
+        self.alphas = alphas.reshape(alphas.shape[0], 1, 1, alphas.shape[1])
+
+    def _mapper_alphas(self):
+        # attn_base[:, :, mapper] (attention_control.py:320): column j of the result is source column mapper[j];
+        # -1 follows Python indexing (last column) and always meets alphas[j] == 0.
+        idx = self.mapper[0].numpy()
+        m = np.zeros((MAX_NUM_WORDS, MAX_NUM_WORDS), dtype=np.float32)
+        for j, w in enumerate(idx):
+            m[int(w) % MAX_NUM_WORDS, j] = 1.0
+        return m, self.alphas.reshape(-1).numpy()
+
+
+class AttentionReweight(AttentionControlEdit):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, equalizer, local_blend=None, controller=None,
+                 device="cuda", tokenizer=None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer, device)
+        self.equalizer = equalizer
+        self.prev_controller = controller
+
+    def _mapper_alphas(self):
+        if self.prev_controller is not None:
+            return self.prev_controller._mapper_alphas()
+        return np.eye(MAX_NUM_WORDS, dtype=np.float32), np.ones(MAX_NUM_WORDS, dtype=np.float32)
+
+    def _equalizer(self):
+        return self.equalizer.reshape(-1).numpy().astype(np.float32)
+
+
+def make_controller(pipeline, prompts, is_replace_controller, cross_replace_steps, self_replace_steps, blend_words=None,
+                    equilizer_params=None, num_ddim_steps=50, device="cuda") -> AttentionControlEdit:
+    """attention_control.py:366-405"""
+    lb = None if blend_words is None else LocalBlend(prompts, blend_words, tokenizer=pipeline.tokenizer, device=device,
+                                                      num_ddim_steps=num_ddim_steps)
+    cls = AttentionReplace if is_replace_controller else AttentionRefine
+    controller = cls(prompts, num_ddim_steps, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                     local_blend=lb, tokenizer=pipeline.tokenizer)
+    if equilizer_params is not None:
+        eq = get_equalizer(prompts[1], equilizer_params["words"], equilizer_params["values"], tokenizer=pipeline.tokenizer)
+        controller = AttentionReweight(prompts, num_ddim_steps, cross_replace_steps=cross_replace_steps,
+                                       self_replace_steps=self_replace_steps, equalizer=eq, local_blend=lb, controller=controller,
+                                       tokenizer=pipeline.tokenizer)
+    return controller
+
+
+def register_attention_control(model, controller):
+    """The reference patches 32 CrossAttention.forward methods here (attention_control.py:12-81).  The native UNet has no
+    Python attention modules; registration just hands the controller to the pipeline's UNet, which turns it into the kernel
+    descriptor at the next call."""
+    model.unet.set_controller(controller)
+    if controller is not None and hasattr(controller, "num_att_layers"):
+        controller.num_att_layers = model.unet.num_att_layers

@@ -1,0 +1,81 @@
+"""P2PEditor with the constructor / call signature of the reference's models/p2p_editor.py:12-45, on the native pipeline.
+
+Implemented method strings (Appendix D of SURVEY.md): "directinversion+p2p" (the hot path),
+"ablation_directinversion_add-target+p2p" / "...add-source+p2p".  Any other string raises the reference's
+NotImplementedError(f"No edit method named {edit_method}") (models/p2p_editor.py:134-135)."""
+import numpy as np
+from PIL import Image
+
+from .config import SD1
+from .p2p.attention_control import AttentionStore, make_controller
+from .p2p.inversion import DirectInversion
+from .p2p.p2p_guidance_forward import (direct_inversion_p2p_guidance_forward,
+                                       direct_inversion_p2p_guidance_forward_add_target)
+from .pipeline import NativePipeline
+from .utils.utils import latent2image, load_512, txt_draw
+
+
+class P2PEditor:
+    def __init__(self, method_list, device, num_ddim_steps=50, *, pipeline=None, cfg=SD1, weight_seed=0, state_dicts=None):
+        self.device = device
+        self.method_list = method_list
+        self.num_ddim_steps = num_ddim_steps
+        if pipeline is None:
+            # The reference loads CompVis/stable-diffusion-v1-4 here (models/p2p_editor.py:23-24).  No checkpoint / network
+            # exists on the target boxes: weights are either passed in (diffusers-layout state dicts) or seeded-synthetic.
+            if state_dicts is not None:
+                pipeline = NativePipeline(cfg, device=device)
+                pipeline.load_state_dict(*state_dicts)
+            else:
+                pipeline = NativePipeline.synthetic(cfg, seed=weight_seed, device=device)
+        self.ldm_stable = pipeline
+        self.scheduler = pipeline.scheduler
+        self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
+
+    def __call__(self, edit_method, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None, quantile=0.7,
+                 use_reconstruction_guidance=False, recon_t=400, recon_lr=0.1, cross_replace_steps=0.4, self_replace_steps=0.6,
+                 blend_word=None, eq_params=None, is_replace_controller=False, use_inversion_guidance=False, dilate_mask=1):
+        if edit_method == "directinversion+p2p":
+            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale,
+                                                   cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                                                   blend_word=blend_word, eq_params=eq_params,
+                                                   is_replace_controller=is_replace_controller)
+        if edit_method in ("ablation_directinversion_add-target+p2p", "ablation_directinversion_add-source+p2p"):
+            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale,
+                                                   cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                                                   blend_word=blend_word, eq_params=eq_params,
+                                                   is_replace_controller=is_replace_controller, add_target=True)
+        raise NotImplementedError(f"No edit method named {edit_method}")
+
+    def edit_image_directinversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
+                                   self_replace_steps=0.6, blend_word=None, eq_params=None, is_replace_controller=False,
+                                   add_target=False, return_stages=False):
+        """models/p2p_editor.py:415-479"""
+        forward = direct_inversion_p2p_guidance_forward_add_target if add_target else direct_inversion_p2p_guidance_forward
+        image_gt = load_512(image_path)
+        side = self.ldm_stable.engine.cfg.sample_size * self.ldm_stable.engine.cfg.vae_scale
+        if side != 512:   # reduced test configurations only; the reference is fixed at 512 (utils/utils.py:45)
+            image_gt = np.array(Image.fromarray(image_gt).resize((side, side)))
+        prompts = [prompt_src, prompt_tar]
+        null_inversion = DirectInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
+        _, _, x_stars, noise_loss_list = null_inversion.invert(image_gt=image_gt, prompt=prompts, guidance_scale=guidance_scale)
+        x_t = x_stars[-1]
+        controller = AttentionStore()
+        reconstruct_latent, x_t = forward(model=self.ldm_stable, prompt=prompts, controller=controller, noise_loss_list=noise_loss_list,
+                                          latent=x_t, num_inference_steps=self.num_ddim_steps, guidance_scale=guidance_scale,
+                                          generator=None)
+        reconstruct_image = latent2image(model=self.ldm_stable.vae, latents=reconstruct_latent)[0]
+        cross_replace_steps = {"default_": cross_replace_steps}
+        controller = make_controller(pipeline=self.ldm_stable, prompts=prompts, is_replace_controller=is_replace_controller,
+                                     cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                                     blend_words=blend_word, equilizer_params=eq_params, num_ddim_steps=self.num_ddim_steps,
+                                     device=self.device)
+        latents, _ = forward(model=self.ldm_stable, prompt=prompts, controller=controller, noise_loss_list=noise_loss_list,
+                             latent=x_t, num_inference_steps=self.num_ddim_steps, guidance_scale=guidance_scale, generator=None)
+        images = latent2image(model=self.ldm_stable.vae, latents=latents)
+        image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
+        panel = Image.fromarray(np.concatenate((image_instruct, image_gt, reconstruct_image, images[-1]), axis=1))
+        if return_stages:
+            return panel, dict(x_stars=x_stars, noise_loss_list=noise_loss_list, reconstruct_latent=reconstruct_latent,
+                               latents=latents, reconstruct_image=reconstruct_image, edited_image=images[-1])
+        return panel

@@ -1,0 +1,107 @@
+"""NativePipeline: the duck-type the reference's P2P code expects from StableDiffusionPipeline
+(models/p2p_editor.py:23-25: `.unet`, `.vae`, `.scheduler`, `.tokenizer`, `.text_encoder`, `.device`), backed by libpnpi.
+
+  model.unet(latents, t, encoder_hidden_states=ctx)["sample"]           inversion.py:273, p2p_guidance_forward.py:109
+  model.unet.in_channels                                                 utils/utils.py:51,54
+  model.vae.encode(x)['latent_dist'].mean / model.vae.decode(z)['sample'] utils/utils.py:61,78
+  model.scheduler.{timesteps, alphas_cumprod, final_alpha_cumprod, config, num_inference_steps, set_timesteps, step}
+"""
+import numpy as np
+import torch
+
+from .config import SD1, ModelConfig
+from .engine import NativeEngine
+from .p2p.scheduler_dev import DDIMSchedulerDev
+from .text import SyntheticTextEncoder, WordTokenizer
+
+
+class _Dist:
+    def __init__(self, mean):
+        self.mean = mean
+
+    def mode(self):
+        return self.mean
+
+
+class NativeVAE:
+    def __init__(self, engine: NativeEngine):
+        self.engine = engine
+        self.device = engine.device
+
+    def encode(self, x):
+        return {"latent_dist": _Dist(self.engine.vae_encode(x))}
+
+    def decode(self, z):
+        return {"sample": self.engine.vae_decode(z)}
+
+    # fused uint8 paths used by utils.latent2image / image2latent
+    def latent2image_u8(self, latents):
+        return self.engine.latent2image(latents.detach()).cpu().numpy()
+
+    def image2latent_u8(self, image):
+        return self.engine.image2latent(np.ascontiguousarray(image))
+
+
+class NativeUNet:
+    """Callable with the reference's UNet protocol.  A registered controller (see p2p.attention_control.register_attention_control)
+    is translated into the kernel descriptor; it applies to batches laid out [uncond_src, uncond_tgt, cond_src, cond_tgt]."""
+
+    def __init__(self, engine: NativeEngine):
+        self.engine = engine
+        self.in_channels = engine.cfg.in_channels
+        self.controller = None
+        cfg = engine.cfg
+        n_attn_blocks = sum(cfg.block_has_attn)
+        self.num_att_layers = 2 * (cfg.layers_per_block * n_attn_blocks + 1 + (cfg.layers_per_block + 1) * n_attn_blocks)
+
+    def set_controller(self, controller):
+        self.controller = controller
+
+    def named_children(self):
+        return iter(())
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
+        rows = sample.shape[0]
+        t = int(timestep)
+        ctrls, cur_step, rpi = None, 0, 1
+        c = self.controller
+        tables = c.tables() if c is not None and hasattr(c, "tables") else None
+        if tables is not None and rows % 4 == 0:
+            ctrls, cur_step, rpi = [tables] * (rows // 4), c.cur_step, 4
+        eps = self.engine.unet(sample, t, encoder_hidden_states, rows_per_image=rpi, ctrls=ctrls, cur_step=cur_step)
+        if c is not None and hasattr(c, "cur_step"):
+            # the reference advances cur_step after the 32nd attention site of every UNet call (attention_control.py:186-189)
+            c.cur_step += 1
+            c.between_steps()
+        return {"sample": eps}
+
+
+class NativePipeline:
+    def __init__(self, cfg: ModelConfig = SD1, device=None, max_unet_rows=4, max_vae_images=2, tokenizer=None, text_encoder=None,
+                 scheduler=None):
+        self.engine = NativeEngine(cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images)
+        self.device = self.engine.device
+        self.unet = NativeUNet(self.engine)
+        self.vae = NativeVAE(self.engine)
+        self.tokenizer = tokenizer or WordTokenizer()
+        self.text_encoder = text_encoder or SyntheticTextEncoder(cfg.cross_dim, device=self.device)
+        self.scheduler = scheduler or DDIMSchedulerDev(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                                       clip_sample=False, set_alpha_to_one=False)
+        self.scheduler.bind(self.engine)
+
+    def to(self, device):
+        return self
+
+    def load_state_dict(self, unet_sd, vae_sd):
+        self.engine.load_state_dict(unet_sd, vae_sd)
+        n, names = self.engine.missing_weights()
+        if n:
+            raise RuntimeError("missing %d weight tensors, e.g. %s" % (n, names[:5]))
+
+    @classmethod
+    def synthetic(cls, cfg: ModelConfig = SD1, seed=0, **kw):
+        """Seeded random-weight pipeline (no checkpoints exist on the build / GPU boxes)."""
+        from . import weights
+        p = cls(cfg, **kw)
+        p.load_state_dict(weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed))
+        return p

@@ -1,0 +1,79 @@
+"""Host-side controller tables (integer / index work): the product's functions must reproduce the reference's tables
+bit-for-bit.  tests/golden/host_tables.json was produced by the reference's own models/p2p/seq_aligner.py,
+utils/utils.py and attention_control.py (oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pnpinversion_amd.p2p import attention_control as ac
+from pnpinversion_amd.p2p import seq_aligner
+from pnpinversion_amd.text import WordTokenizer
+from pnpinversion_amd.utils.utils import get_time_words_attention_alpha, get_word_inds
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_tables.json")))
+
+
+@pytest.mark.parametrize("e", G, ids=[e["src"][:20] for e in G])
+def test_tables_match_reference(e):
+    tok = WordTokenizer()
+    src, tgt, (w0, w1) = e["src"], e["tgt"], e["blend"]
+    assert get_word_inds(src, w0, tok).tolist() == e["word_inds_src"]
+    assert get_word_inds(tgt, w1, tok).tolist() == e["word_inds_tgt"]
+    assert get_word_inds(tgt, 1, tok).tolist() == e["word_inds_int"]
+    m, a = seq_aligner.get_refinement_mapper([src, tgt], tok)
+    assert m[0].tolist() == e["refine_mapper"]
+    assert a[0].tolist() == e["refine_alphas"]
+    if "replace_mapper" in e:
+        assert seq_aligner.get_replacement_mapper([src, tgt], tok)[0].tolist() == e["replace_mapper"]
+    else:
+        with pytest.raises(ValueError, match="attention replacement edit can only be applied on prompts with the same length"):
+            seq_aligner.get_replacement_mapper([src, tgt], tok)
+    for steps in (50, 2):
+        al = get_time_words_attention_alpha([src, tgt], steps, {"default_": 0.4}, tok)
+        assert al.reshape(steps + 1, 77).tolist() == e["cross_alpha_%d" % steps]
+    assert ac.get_equalizer(tgt, (w1,), (2,), tokenizer=tok)[0].tolist() == e["equalizer"]
+    lb = ac.LocalBlend([src, tgt], ((w0,), (w1,)), tokenizer=tok, num_ddim_steps=50)
+    assert lb.alpha_layers.reshape(2, 77).tolist() == e["lb_alpha"]
+    assert lb.start_blend == e["lb_start"]
+
+
+def test_controller_descriptor_semantics():
+    """The declarative tables reproduce the reference's per-row edit formulas (attention_control.py:269-345) exactly."""
+    import torch
+    from types import SimpleNamespace
+    tok = WordTokenizer()
+    e = G[0]
+    prompts = [e["src"], e["tgt"]]
+    pipe = SimpleNamespace(tokenizer=tok)
+    rng = np.random.default_rng(0)
+    base = torch.from_numpy(rng.random((8, 5, 77), dtype=np.float32))
+    repl = torch.from_numpy(rng.random((1, 8, 5, 77), dtype=np.float32))
+    for is_replace, blend, eq in ((False, ((e["blend"][0],), (e["blend"][1],)), {"words": (e["blend"][1],), "values": (2,)}),
+                                  (True, None, None), (False, None, None)):
+        c = ac.make_controller(pipe, prompts, is_replace, {"default_": 0.4}, 0.6, blend, eq, num_ddim_steps=50)
+        t = c.tables()
+        assert t.self_range == (0, 30) and t.cross_alpha.shape == (51, 77)
+        mm, al, eqv = torch.from_numpy(t.mapper), torch.from_numpy(t.alphas), torch.from_numpy(t.equalizer)
+        for step in (0, 19, 20, 50):
+            a_t = torch.from_numpy(t.cross_alpha[step])
+            # reference formulation
+            if is_replace:
+                new = torch.einsum("hpw,bwn->bhpn", base, torch.from_numpy(np.asarray(e["replace_mapper"], dtype=np.float32))[None])
+            else:
+                idx = torch.tensor(e["refine_mapper"])
+                ra = torch.tensor(e["refine_alphas"]).reshape(1, 1, 1, 77)
+                new = base[:, :, idx[None]].permute(2, 0, 1, 3) * ra + repl * (1 - ra)
+            if eq is not None:
+                new = new * torch.tensor(e["equalizer"]).reshape(1, 1, 1, 77)
+            ref = new * a_t + (1 - a_t) * repl
+            # declarative formulation consumed by the HIP kernel
+            c1 = a_t * eqv * al
+            c2 = a_t * eqv * (1 - al) + (1 - a_t)
+            got = c1 * torch.einsum("hpw,wn->hpn", base, mm)[None] + c2 * repl
+            assert torch.allclose(got, ref, atol=1e-6), (is_replace, step)
+        if blend is not None:
+            assert t.lb_alpha.tolist() == e["lb_alpha"] and t.lb_start == 10 and abs(t.lb_threshold - 0.3) < 1e-7
+        else:
+            assert t.lb_alpha is None

@@ -1,0 +1,116 @@
+"""Pins the CPU oracle (oracle/sd_oracle.py, oracle/p2p_oracle.py) against outputs of the REFERENCE's own code.
+
+The reference holds no tests / golden vectors for this path; tests/golden/*.npz were produced by running the
+reference's modules (imported from /root/reference by oracle/ref_shim.py) on the seeded weights -- oracle/make_golden.py.
+fp32 vs fp32: differences are summation-order round-off only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import p2p_oracle as po
+from oracle import sd_oracle
+from pnpinversion_amd import weights
+from pnpinversion_amd.config import SD1, SMALL64, TINY16
+from pnpinversion_amd.p2p import attention_control as ac
+from pnpinversion_amd.text import WordTokenizer
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny", TINY16), ("sd1", SD1)])
+def test_unet_and_vae_match_reference(name, cfg):
+    g = load("unet_%s.npz" % name)
+    seed = int(g["seed"])
+    usd = weights.unet_state_dict(cfg, seed)
+    with torch.no_grad():
+        eps = sd_oracle.unet_forward(usd, cfg, torch.from_numpy(g["latents"]), int(g["t"]), torch.from_numpy(g["context"]).float())
+    assert rel(eps, g["eps"]) < 2e-5
+    del usd
+    v = load("vae_%s.npz" % name)
+    vsd = weights.vae_state_dict(cfg, int(v["seed"]))
+    with torch.no_grad():
+        mean = sd_oracle.vae_encode_mean(vsd, cfg, torch.from_numpy(v["image"]).float())
+        dec = sd_oracle.vae_decode(vsd, cfg, torch.from_numpy(v["z"]))
+    assert rel(mean, v["mean"]) < 2e-5
+    assert rel(dec, v["dec"]) < 2e-5
+
+
+def test_scheduler_tables_and_step_formulas():
+    ac_ = po.alphas_cumprod()
+    # SURVEY.md Appendix C anchors
+    assert abs(ac_[0].item() - 0.999149978) < 1e-7 and abs(ac_[980].item() - 0.005843779) < 1e-8
+    assert po.make_timesteps(50).tolist() == list(range(980, -1, -20))
+    g = torch.Generator().manual_seed(0)
+    x, e = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    for t in (980, 500, 20, 0):
+        a_t, a_p = po.prev_alphas(ac_, ac_[0], t, 20)
+        # DirectInversion.prev_step as written (inversion.py:247-253), evaluated by torch
+        x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+        ref = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+        assert torch.allclose(po.ddim_move(x, e, float(a_t), float(a_p)), ref, atol=2e-6, rtol=0)
+        a_f, a_n = po.next_alphas(ac_, ac_[0], t, 20)
+        x0 = (x - (1 - a_f) ** 0.5 * e) / a_f ** 0.5
+        ref = a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * e
+        assert torch.allclose(po.ddim_move(x, e, float(a_f), float(a_n)), ref, atol=2e-6, rtol=0)
+
+
+def _tables_from_product(g, steps):
+    """Controller tables for the oracle, built by the product's host code (itself pinned by test_host_tables.py)."""
+    from types import SimpleNamespace
+    tok = WordTokenizer()
+    prompts = [str(g["src"]), str(g["tgt"])]
+    w0, w1 = [str(x) for x in g["blend"]]
+    use_blend, is_replace = bool(g["use_blend"]), bool(g["is_replace"])
+    c = ac.make_controller(SimpleNamespace(tokenizer=tok), prompts, is_replace, {"default_": 0.4}, 0.6,
+                           ((w0,), (w1,)) if use_blend else None, {"words": (w1,), "values": (2,)} if use_blend else None,
+                           num_ddim_steps=steps)
+    inner = c.prev_controller if isinstance(c, ac.AttentionReweight) else c
+    t = {"cross_alpha": c.cross_replace_alpha.reshape(steps + 1, 77), "self_range": c.num_self_replace,
+         "equalizer": c.equalizer.reshape(-1) if isinstance(c, ac.AttentionReweight) else None, "lb": None}
+    if isinstance(inner, ac.AttentionReplace):
+        t["kind"], t["mapper"] = "replace", inner.mapper[0]
+    else:
+        t["kind"], t["mapper"], t["alphas"] = "refine", inner.mapper[0], inner.alphas.reshape(-1)
+    if c.local_blend is not None:
+        t["lb"] = {"alpha_layers": c.local_blend.alpha_layers.reshape(2, 77), "start": c.local_blend.start_blend, "th": 0.3}
+    return t
+
+
+@pytest.mark.parametrize("name", ["refine", "replace"])
+def test_loops_and_controllers_match_reference(name):
+    """The reference's P2PEditor("directinversion+p2p") stage outputs vs the oracle's loops (SMALL64, 2+2 steps)."""
+    g = load("e2e_%s.npz" % name)
+    cfg, steps = SMALL64, int(g["steps"])
+    usd = weights.unet_state_dict(cfg, 2)
+    ctx = torch.from_numpy(g["context"]).float()
+    x_stars = torch.from_numpy(g["x_stars"])
+    ac_ = po.alphas_cumprod()
+    ts = po.make_timesteps(steps)
+
+    def unet_fn(lat, t, c, hook):
+        with torch.no_grad():
+            return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    if name == "refine":   # inversion + offsets once (the heavier half of the run)
+        lat = po.ddim_loop(unet_fn, x_stars[0], ctx[2:3], ts, ac_, ac_[0])
+        assert rel(torch.stack(lat), x_stars) < 2e-5
+        nl = po.offset_calculate(unet_fn, [x for x in x_stars], ctx, ts, ac_, ac_[0], 7.5)
+        scale = x_stars[0].norm().item() / x_stars[0].numel() ** 0.5
+        assert (torch.stack(nl) - torch.from_numpy(g["noise_loss"])).abs().max().item() < 5e-5 * max(1.0, scale)
+    nl_ref = [x for x in torch.from_numpy(g["noise_loss"])]
+    ctrl = po.EditController(32, _tables_from_product(g, steps))
+    out = po.guidance_forward(unet_fn, x_stars[-1], ctx, nl_ref, ctrl, ts, ac_, ac_[0], 7.5)
+    assert rel(out, g["edited_latents"]) < 5e-5, rel(out, g["edited_latents"])
+    # Note D of SURVEY.md: the source branch reproduces x*_0
+    assert rel(out[0], x_stars[0][0]) < 1e-4
