@@ -425,7 +425,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
       const bool lb = cd.lb_any && t.lb_slot0 >= 0 && N == c->unet.lb_tokens;
       e.lb_alpha = lb ? cd.lb_alpha : nullptr;
       e.lb_acc = lb ? cd.lb_acc : nullptr;
-      e.lb_slot0 = t.lb_slot0; e.lb_nslots = c->unet.lb_nslots;
+      e.lb_slot0 = t.lb_slot0; e.lb_nslots = c->unet.lb_nslots; e.write_src = 0;
       PROF(PNPI_KC_ATTN_EDIT, 4.0 * 2 * cd.npairs * t.heads * (double)N * T * t.dh, 0.0, launch_attn_cross_edit(e, c->st));
     }
   }
@@ -675,7 +675,7 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
     int src = i * 4 + 2, tgt = i * 4 + 3;
     rep[tgt * 4 + 1] = src; rep[tgt * 4 + 2] = src;  // q and k of the target row come from the source row
     pairs.push_back(src); pairs.push_back(tgt);
-    is_pair_row[src] = is_pair_row[tgt] = true;
+    is_pair_row[tgt] = true;   // only the target row leaves the plain path; the source row stays bit-identical to it
     cd.pair_img.push_back(i);
   }
   for (int r = 0; r < rows; ++r) if (!is_pair_row[r]) { plain.push_back(r); plain.push_back(r); plain.push_back(r); plain.push_back(r); }
@@ -1236,7 +1236,7 @@ int pnpi_op_cross_edit(pnpi_ctx* c, const void* q, int ldq, int q_off, const voi
   CrossEditP e; e.q = (const half_t*)q; e.ldq = ldq; e.q_off = q_off; e.k = (const half_t*)k; e.ldk = ldk; e.k_off = k_off;
   e.vt = (const half_t*)vt; e.ldv = ldv; e.o = (half_t*)o; e.ldo = ldo; e.heads = heads; e.Nq = Nq; e.Nk = Nk; e.Dp = Dp; e.dh = dh;
   e.scale = scale; e.pairs = pairs_dev; e.npairs = npairs; e.mmatT = (const half_t*)mmatT; e.c1 = c1; e.c2 = c2;
-  e.lb_alpha = lb_alpha; e.lb_acc = lb_acc; e.lb_slot0 = lb_slot0; e.lb_nslots = lb_nslots;
+  e.lb_alpha = lb_alpha; e.lb_acc = lb_acc; e.lb_slot0 = lb_slot0; e.lb_nslots = lb_nslots; e.write_src = 1;
   CK(launch_attn_cross_edit(e, c->st));
   return 0;
 }

@@ -324,9 +324,11 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
     }
   }
 
-  // O = P V for both rows
+  // O = P V.  By default only the TARGET row is written: the source row's output comes from the plain flash kernel, so that it
+  // is bit-identical to the controller-free passes (the direct-inversion offset only cancels against an identical forward).
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
+    if (which == 0 && !p.write_src) continue;
     half8 pf[3][2];
 #pragma unroll
     for (int st = 0; st < 3; ++st)

@@ -83,6 +83,7 @@ struct CrossEditP {
   const float* lb_alpha;          // device [npairs][2][96] LocalBlend token selectors (nullable)
   float* lb_acc;                  // device [npairs][nslots][2][Nq] accumulators (nullable)
   int lb_slot0, lb_nslots;        // this layer's first slot (slot = lb_slot0 + head)
+  int write_src;                  // also store the source row's output (tests); the executor leaves that to the flash kernel
 };
 int launch_attn_cross_edit(const CrossEditP& p, hipStream_t st);
 

@@ -265,13 +265,11 @@ def test_cross_edit(ctx, Nq, dh, Dp, with_lb):
 
 
 # ------------------------------------------------------------------------------------------------ step kernels (bit exact)
-def ref_alphas():
-    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
-    return torch.cumprod(1.0 - betas, dim=0)
-
-
 def test_step_kernels_bit_exact(ctx):
-    ac = ref_alphas()
+    """DDIM moves / CFG / the direct-inversion lines are bit-exact against the oracle (oracle/p2p_oracle.py, which evaluates
+    the reference formulas with correctly rounded fp32 scalars) and within 1e-6 of the formulas as torch evaluates them."""
+    from oracle import p2p_oracle as po
+    ac = po.alphas_cumprod()
     final = ac[0]
     arr = (C.c_float * 1000)(*ac.tolist())
     ctx.call("pnpi_set_scheduler", arr, 1000, float(final))
@@ -279,41 +277,39 @@ def test_step_kernels_bit_exact(ctx):
     x = torch.randn(2, 4, 16, 16, generator=g)
     e4 = torch.randn(4, 4, 16, 16, generator=g)
     xd, e4d = x.to(DEV), e4.to(DEV)
-    for t in (980, 500, 20, 0):
+    for t in (980, 500, 480, 20, 0):
         # next_step (inversion.py:262-270)
-        tp = min(t - 20, 999)
-        a_t = ac[tp] if tp >= 0 else final
-        a_n = ac[t]
-        e = e4[:2]
-        x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
-        ref = a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * e
-        out = torch.empty_like(x, device=DEV)
-        ed = e.contiguous().to(DEV)
+        e = e4[:2].contiguous()
+        a_f, a_n = po.next_alphas(ac, final, t, 20)
+        ref = po.ddim_move(x, e, float(a_f), float(a_n))
+        out = torch.empty(2, 4, 16, 16, device=DEV)
+        ed = e.to(DEV)
         ctx.call("pnpi_ddim_next_step", ptr(ed), t, 20, ptr(xd), x.numel(), ptr(out))
         assert torch.equal(out.cpu(), ref), t
+        x0 = (x - (1 - a_f) ** 0.5 * e) / a_f ** 0.5
+        assert torch.allclose(out.cpu(), a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * e, atol=2e-6, rtol=0)
         # CFG + prev_step + offset (inversion.py:383-389)
-        a_t = ac[t]
-        a_p = ac[t - 20] if t - 20 >= 0 else final
+        a_t, a_p = po.prev_alphas(ac, final, t, 20)
         eu, ec = e4.chunk(2)
         eg = eu + 7.5 * (ec - eu)
-        x0 = (x - (1 - a_t) ** 0.5 * eg) / a_t ** 0.5
-        prev = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eg
+        prev = po.ddim_move(x, eg, float(a_t), float(a_p))
         target = torch.randn(1, 4, 16, 16, generator=g)
         loss = target - prev
         cur = prev + loss
         off = torch.empty(2, 4, 16, 16, device=DEV)
         xo = torch.empty(2, 4, 16, 16, device=DEV)
         td = target.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td),
-                 ptr(off), ptr(xo))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), ptr(off), ptr(xo))
         assert torch.equal(off.cpu(), loss) and torch.equal(xo.cpu(), cur), t
         # guidance step with noise_loss on the first row only (p2p_guidance_forward.py:110-114)
         nl = torch.randn(2, 4, 16, 16, generator=g)
         ref2 = torch.cat((prev[:1] + nl[:1], prev[1:]))
         nld = nl.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, None,
-                 ptr(xo))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, None, ptr(xo))
         assert torch.equal(xo.cpu(), ref2), t
+        # DDIMSchedulerDev.step == prev_step
+        ctx.call("pnpi_ddim_prev_step", ptr(ed), t, 20, ptr(xd), x.numel(), ptr(out))
+        assert torch.equal(out.cpu(), po.ddim_move(x, e, float(a_t), float(a_p))), t
 
 
 def test_local_blend(ctx):

@@ -1,0 +1,152 @@
+"""Loop-level parity of the HIP path (through the C ABI and the reference-shaped Python API) against
+  (a) the committed golden stage outputs of the REFERENCE's own P2PEditor run (tests/golden/e2e_*.npz, SMALL64, 2+2 steps), and
+  (b) the CPU oracle on other seeds / configurations.
+Tolerances (fp16 activations vs the fp32 reference; k = number of UNet steps the error has compounded over):
+  DDIM latents rel-L2 <= 4e-3 * sqrt(k); direct-inversion offsets: abs error <= 1.5e-2 * rms(latent) (an offset is a small
+  difference of two latents); edited latents rel-L2 <= 1.5e-2 outside LocalBlend mask flips (<= 0.5 % of latent pixels may
+  differ by a mask decision); decoded images: mean |diff| <= 2/255."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import p2p_oracle as po  # noqa: E402   (checker only)
+from oracle import sd_oracle  # noqa: E402
+from pnpinversion_amd import weights  # noqa: E402
+from pnpinversion_amd.config import SMALL64, TINY16  # noqa: E402
+from pnpinversion_amd.p2p import attention_control as ac  # noqa: E402
+from pnpinversion_amd.p2p_editor import P2PEditor  # noqa: E402
+from pnpinversion_amd.pipeline import NativePipeline  # noqa: E402
+from pnpinversion_amd.text import SyntheticTextEncoder  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def masked_rel(a, b, tol_frac=0.005, pix_tol=0.25):
+    """rel-L2 ignoring at most tol_frac of the pixels (LocalBlend mask decisions that flip at the 0.3 threshold)."""
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    d = (a - b).abs().amax(dim=-3)                # per latent pixel
+    bad = d > pix_tol
+    frac = bad.float().mean().item()
+    keep = (~bad).unsqueeze(-3).expand_as(a)
+    r = ((a - b)[keep].norm() / b[keep].norm()).item()
+    return r, frac
+
+
+@pytest.fixture(scope="module")
+def small64():
+    cfg = SMALL64
+    pipe = NativePipeline(cfg, max_unet_rows=4, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    yield pipe
+    pipe.engine.close()
+
+
+@pytest.mark.parametrize("name", ["refine", "replace"])
+def test_loops_against_reference_golden(small64, name):
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % name))
+    pipe = small64
+    eng = pipe.engine
+    steps = int(g["steps"])
+    pipe.scheduler.set_timesteps(steps)
+    ts = pipe.scheduler.timesteps.numpy()
+    ctx = torch.from_numpy(g["context"]).float()
+    x_stars = torch.from_numpy(g["x_stars"])                       # [steps+1, 1, 4, 64, 64]
+    # DDIM inversion (inversion.py:308-319)
+    got = eng.ddim_invert(x_stars[0], ctx[2:3], ts)
+    assert rel(got, x_stars) < 4e-3 * steps ** 0.5, rel(got, x_stars)
+    # offsets (inversion.py:375-391), from the reference's own trajectory.  (The last offset is ~1e-8: the t=0 step is the
+    # identity map, SURVEY Appendix C -- so the error is measured against the overall offset scale, not per step.)
+    nl = eng.offset_calculate(x_stars, ctx[None], ts, 7.5)          # [steps, 1, 2, 4, 64, 64]
+    ref_nl = torch.from_numpy(g["noise_loss"])
+    assert rel(nl[:, 0], ref_nl) < 1.5e-2, rel(nl[:, 0], ref_nl)
+    # reconstruct pass (AttentionStore) and edit pass with the controller.  The offsets fed back are the NATIVE ones, as in
+    # the real pipeline: the source row is (prev + offset) with |prev|, |offset| >> |x*|, so only a consistent pair cancels.
+    src, tgt = str(g["src"]), str(g["tgt"])
+    w0, w1 = [str(x) for x in g["blend"]]
+    use_blend, is_replace = bool(g["use_blend"]), bool(g["is_replace"])
+    rec = eng.edit_loop(x_stars[-1], ctx[None], nl, None, ts, 7.5)[0]
+    assert rel(rec[1], g["reconstruct_latent"][1]) < 1.5e-2, rel(rec[1], g["reconstruct_latent"][1])
+    assert rel(rec[0], x_stars[0][0]) < 2e-2, rel(rec[0], x_stars[0][0])
+    ctrl = ac.make_controller(pipe, [src, tgt], is_replace, {"default_": 0.4}, 0.6, ((w0,), (w1,)) if use_blend else None,
+                              {"words": (w1,), "values": (2,)} if use_blend else None, num_ddim_steps=steps)
+    out = eng.edit_loop(x_stars[-1], ctx[None], nl, [ctrl.tables()], ts, 7.5)[0]
+    ref = torch.from_numpy(g["edited_latents"])
+    r, frac = masked_rel(out[1], ref[1])
+    assert frac <= 0.005 and r < 1.5e-2, (r, frac)
+    # the source branch reproduces x*_0 (SURVEY Note D)
+    assert rel(out[0], x_stars[0][0]) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["refine", "replace"])
+def test_p2p_editor_end_to_end_against_reference_golden(small64, name):
+    """Drop-in API: P2PEditor(...)(edit_method, image, prompts, ...) -> 4-panel PIL image; compared with the panels the
+    reference's own P2PEditor produced from the same image / prompts / weights (stored 4x subsampled)."""
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % name))
+    steps = int(g["steps"])
+    ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=small64)
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    w0, w1 = [str(x) for x in g["blend"]]
+    use_blend = bool(g["use_blend"])
+    panel, st = ed.edit_image_directinversion(img, str(g["src"]), str(g["tgt"]), guidance_scale=7.5, cross_replace_steps=0.4,
+                                              self_replace_steps=0.6, blend_word=((w0,), (w1,)) if use_blend else None,
+                                              eq_params={"words": (w1,), "values": (2,)} if use_blend else None,
+                                              is_replace_controller=bool(g["is_replace"]), return_stages=True)
+    assert panel.size == (2048, 512)
+    xs = torch.stack([x.cpu() for x in st["x_stars"]])
+    assert rel(xs, g["x_stars"]) < 6e-3, rel(xs, g["x_stars"])
+    r, frac = masked_rel(st["latents"], torch.from_numpy(g["edited_latents"]), tol_frac=0.01)
+    assert frac <= 0.01 and r < 2.5e-2, (r, frac)
+    p = np.array(panel)
+    rec_small, edit_small = p[::4, 1024:1536:4], p[::4, 1536::4]
+    assert np.abs(rec_small.astype(np.int32) - g["recon_image_small"].astype(np.int32)).mean() < 2.0
+    assert np.abs(edit_small.astype(np.int32) - g["edited_image_small"].astype(np.int32)).mean() < 4.0
+    with pytest.raises(NotImplementedError, match="No edit method named"):
+        ed("no-such-method+p2p", img, "a", "b")
+
+
+def test_loops_against_oracle_tiny():
+    """Other seeds, TINY16 (16x16 latents), 5+5 steps: native loops vs the CPU oracle end to end (Replace controller)."""
+    cfg = TINY16
+    usd = weights.unet_state_dict(cfg, 5)
+    pipe = NativePipeline(cfg, max_unet_rows=4, max_vae_images=1, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=3))
+    pipe.load_state_dict(usd, weights.vae_state_dict(cfg, 5))
+    eng = pipe.engine
+    steps = 5
+    pipe.scheduler.set_timesteps(steps)
+    ts = pipe.scheduler.timesteps.numpy()
+    g = torch.Generator().manual_seed(21)
+    z0 = torch.randn(1, 4, 16, 16, generator=g)
+    ctx = weights.synth_context(cfg, 4, seed=22)
+    ac_ = po.alphas_cumprod()
+
+    def unet_fn(lat, t, c, hook):
+        with torch.no_grad():
+            return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    ref_lat = po.ddim_loop(unet_fn, z0, ctx[2:3], po.make_timesteps(steps), ac_, ac_[0])
+    got_lat = eng.ddim_invert(z0, ctx[2:3], ts)
+    assert rel(got_lat, torch.stack(ref_lat)) < 4e-3 * steps ** 0.5
+    ref_nl = po.offset_calculate(unet_fn, ref_lat, ctx, po.make_timesteps(steps), ac_, ac_[0], 7.5)
+    got_nl = eng.offset_calculate(torch.stack(ref_lat), ctx[None], ts, 7.5)
+    assert rel(got_nl[:, 0], torch.stack(ref_nl)) < 1.5e-2, rel(got_nl[:, 0], torch.stack(ref_nl))
+    prompts = ["a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate"]
+    c = ac.make_controller(pipe, prompts, True, {"default_": 0.4}, 0.6, None, {"words": ("square",), "values": (2,)},
+                           num_ddim_steps=steps)
+    tables = {"kind": "replace", "mapper": c.prev_controller.mapper[0], "equalizer": c.equalizer.reshape(-1),
+              "cross_alpha": c.cross_replace_alpha.reshape(steps + 1, 77), "self_range": c.num_self_replace, "lb": None}
+    ref_out = po.guidance_forward(unet_fn, ref_lat[-1], ctx, ref_nl, po.EditController(32, tables), po.make_timesteps(steps), ac_,
+                                  ac_[0], 7.5)
+    got_out = eng.edit_loop(ref_lat[-1], ctx[None], got_nl, [c.tables()], ts, 7.5)[0]
+    assert rel(got_out[1], ref_out[1]) < 2e-2, rel(got_out[1], ref_out[1])
+    assert rel(got_out[0], z0[0]) < 2e-2, rel(got_out[0], z0[0])
+    eng.close()
