@@ -102,6 +102,9 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch ships its own libamdhip64; it must be the first (and only) HIP runtime mapped into the process, otherwise this
+    # library would initialise a second runtime that sees no device.
+    import torch  # noqa: F401
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise ImportError(

@@ -18,16 +18,26 @@ def arena_tensor(engine):
     return torch.as_tensor(_DevView(ptr, nbytes), device=engine.device)
 
 
+def broadcast_buffer(t, src=0, group=None, chunk_bytes=1 << 30):
+    """Broadcast a flat uint8 buffer in <= 1 GiB pieces (few, large messages: xGMI links are per-peer, a broadcast from one
+    rank is bounded by a single link's bandwidth whatever the piece count)."""
+    import torch.distributed as dist
+    n = t.numel()
+    for off in range(0, n, chunk_bytes):
+        dist.broadcast(t[off:min(n, off + chunk_bytes)], src=src, group=group)
+    return n
+
+
 def broadcast_weights(engine, src=0, group=None):
-    """RCCL broadcast of the whole arena from `src`; receivers mark their slots loaded."""
+    """RCCL broadcast of the whole packed arena from `src`; receivers mark their weight slots loaded."""
     import torch.distributed as dist
     t = arena_tensor(engine)
     torch.cuda.synchronize(engine.device)
-    dist.broadcast(t, src=src, group=group)
+    n = broadcast_buffer(t, src=src, group=group)
     torch.cuda.synchronize(engine.device)
     if dist.get_rank(group) != src:
         engine.mark_all_loaded()
-    return t.numel()
+    return n
 
 
 def shard_items(items, rank=None, world=None):

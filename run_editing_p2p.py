@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""PIE-Bench sweep driver with the CLI of the reference's run_editing_p2p.py (same flags, same output tree, same
+skip-if-exists resume), on the MI355X-native P2PEditor.  Under torch.distributed.run (one process per GPU) the ordered work
+list is sharded round-robin over the ranks and the weight arena is broadcast once from rank 0 over RCCL / xGMI; there is no
+per-image communication."""
+import argparse
+import json
+import os
+import random
+
+import numpy as np
+import torch
+from PIL import Image
+
+from pnpinversion_amd.distributed import broadcast_weights, shard_items
+from pnpinversion_amd.p2p_editor import P2PEditor
+
+
+def mask_decode(encoded_mask, image_shape=(512, 512)):
+    """PIE-Bench run-length mask: [start0, len0, start1, len1, ...] over the flattened image; the border is forced to 1
+    (run_editing_p2p.py:11-27)."""
+    n = image_shape[0] * image_shape[1]
+    mask = np.zeros(n)
+    runs = np.asarray(encoded_mask, dtype=np.int64).reshape(-1, 2)
+    for start, length in runs:
+        mask[start:start + min(length, n - start)] = 1
+    mask = mask.reshape(image_shape)
+    mask[0, :] = mask[-1, :] = 1
+    mask[:, 0] = mask[:, -1] = 1
+    return mask
+
+
+def setup_seed(seed=1234):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rerun_exist_images", action="store_true")
+    ap.add_argument("--data_path", type=str, default="data")
+    ap.add_argument("--output_path", type=str, default="output")
+    ap.add_argument("--edit_category_list", nargs="+", type=str, default=[str(i) for i in range(10)])
+    ap.add_argument("--edit_method_list", nargs="+", type=str, default=["directinversion+p2p"])
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import SD1
+    from pnpinversion_amd.pipeline import NativePipeline
+    pipe = NativePipeline(SD1, device="cuda:%d" % local_rank)
+    if rank == 0:
+        pipe.load_state_dict(weights.unet_state_dict(SD1, 0), weights.vae_state_dict(SD1, 0))   # no SD checkpoint offline
+    if world > 1:
+        broadcast_weights(pipe.engine, src=0)
+    editor = P2PEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=50, pipeline=pipe)
+
+    with open(os.path.join(args.data_path, "mapping_file.json")) as f:
+        instructions = json.load(f)
+    work = [(k, v) for k, v in instructions.items() if v["editing_type_id"] in args.edit_category_list]
+    for key, item in shard_items(work, rank, world):
+        src = item["original_prompt"].replace("[", "").replace("]", "")
+        tgt = item["editing_prompt"].replace("[", "").replace("]", "")
+        image_path = os.path.join(args.data_path, "annotation_images", item["image_path"])
+        blended = item["blended_word"].split(" ") if item["blended_word"] != "" else []
+        _ = Image.fromarray(np.uint8(mask_decode(item["mask"])[:, :, None].repeat(3, 2))).convert("L")   # unused, as in the reference
+        for method in args.edit_method_list:
+            out_path = image_path.replace(args.data_path, os.path.join(args.output_path, method))
+            if os.path.exists(out_path) and not args.rerun_exist_images:
+                print(f"skip image [{image_path}] with [{method}]")
+                continue
+            print(f"editing image [{image_path}] with [{method}]")
+            setup_seed()
+            edited = editor(method, image_path=image_path, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5,
+                            cross_replace_steps=0.4, self_replace_steps=0.6,
+                            blend_word=((blended[0],), (blended[1],)) if blended else None,
+                            eq_params={"words": (blended[1],), "values": (2,)} if blended else None,
+                            proximal="l0", quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400)
+            os.makedirs(os.path.dirname(out_path), exist_ok=True)
+            edited.save(out_path)
+            print("finish")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

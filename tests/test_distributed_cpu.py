@@ -1,0 +1,56 @@
+"""The N > 1 path on CPU (gloo, world_size 2): static image sharding and the start-up weight-buffer broadcast
+(on the GPU box the same code runs over RCCL / xGMI with the packed weight arena as the buffer)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pnpinversion_amd.distributed import broadcast_buffer, shard_items
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    items = ["img_%03d" % i for i in range(11)]
+    mine = shard_items(items)                    # reads RANK / WORLD_SIZE like the sweep driver
+    buf = torch.arange(3000, dtype=torch.int64).to(torch.uint8) if rank == 0 else torch.zeros(3000, dtype=torch.uint8)
+    broadcast_buffer(buf, src=0, chunk_bytes=1024)   # several pieces
+    # a max-over-ranks timing reduction like bench.py's
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, mine, int(buf.to(torch.int64).sum()), float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_broadcast():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    items = ["img_%03d" % i for i in range(11)]
+    assert sorted(res[0][1] + res[1][1]) == items and not set(res[0][1]) & set(res[1][1])
+    assert res[0][1] == items[0::2] and res[1][1] == items[1::2]
+    expect = int(torch.arange(3000, dtype=torch.int64).to(torch.uint8).to(torch.int64).sum())
+    assert res[0][2] == expect and res[1][2] == expect
+    assert res[0][3] == 2.0 and res[1][3] == 2.0
+
+
+def test_single_rank_is_identity():
+    assert shard_items(list(range(5)), rank=0, world=1) == list(range(5))
