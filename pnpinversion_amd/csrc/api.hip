@@ -2,6 +2,7 @@
 // See include/pnpi.h for the reference interface each entry point replaces.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "model.h"
@@ -262,9 +263,9 @@ static void prof_open(pnpi_ctx* c, ProfRec& r) {
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
   (void)hipEventRecord(r.a, c->st);
 }
-static void prof_close(pnpi_ctx* c, ProfRec& r, int cls, double flops, double bytes) {
+static void prof_close(pnpi_ctx* c, ProfRec& r, int cls, double flops, double bytes, int M = 0, int N = 0, int K = 0, int ks = 0) {
   (void)hipEventRecord(r.b, c->st);
-  r.cls = cls; r.flops = flops; r.bytes = bytes;
+  r.cls = cls; r.flops = flops; r.bytes = bytes; r.M = M; r.N = N; r.K = K; r.ksize = ks;
   c->prof.push_back(r);
 }
 #define PROF(cls, flops, bytes, expr)                         \
@@ -299,7 +300,7 @@ static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops) {
     ProfRec pr; prof_open(c, pr);
     int used = 0;
     int r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, &used);
-    prof_close(c, pr, used, alg_flops, 0.0);
+    prof_close(c, pr, used, alg_flops, 0.0, p.M, p.N, p.K, p.ksize);
     return r;
   }
   return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
@@ -810,7 +811,7 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
   const int C0 = g.block_out_channels[0], TE = 4 * C0;
   c->splitk_bytes = (size_t)96 << 20;
   CKH(hipMalloc((void**)&c->splitk_ws, c->splitk_bytes));
-  size_t gnp = (size_t)(max_unet_rows > max_vae_images ? max_unet_rows : max_vae_images) * 128 * 64 * 2 * sizeof(float);
+  size_t gnp = (size_t)(max_unet_rows > max_vae_images ? max_unet_rows : max_vae_images) * (128 * 64 * 2 + 4096 * 2) * sizeof(float);
   CKH(hipMalloc((void**)&c->gn_partial, gnp));
   CKH(hipMalloc((void**)&c->temb_h, TE * sizeof(float)));
   CKH(hipMalloc((void**)&c->temb_emb, TE * sizeof(float)));
@@ -960,6 +961,17 @@ int pnpi_profile_end(pnpi_ctx* c, pnpi_kernel_stats* out) {
   if (!c || !out) return PNPI_EINVAL;
   c->prof_on = false;
   CKH(hipStreamSynchronize(c->st));
+  if (const char* path = getenv("PNPI_PROFILE_DUMP")) {   // per-launch records for tools/ (class, M, N, K, ksize, us)
+    if (FILE* f = fopen(path, "w")) {
+      fprintf(f, "cls,M,N,K,ksize,us,flops\n");
+      for (ProfRec& r : c->prof) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        fprintf(f, "%d,%d,%d,%d,%d,%.3f,%.0f\n", r.cls, r.M, r.N, r.K, r.ksize, ms * 1e3, r.flops);
+      }
+      fclose(f);
+    }
+  }
   memset(out, 0, sizeof(pnpi_kernel_stats) * PNPI_KC_COUNT);
   for (ProfRec& r : c->prof) {
     float ms = 0.f;

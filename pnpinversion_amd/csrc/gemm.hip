@@ -9,6 +9,8 @@
 // group holds 4 consecutive output channels of one pixel (8-byte NHWC stores, vector bias loads).
 // global -> registers -> LDS staging (the conv gather needs per-lane predication, which LDS-DMA cannot do), LDS rows
 // padded by 16 B so that ds_read_b128 fragment reads are bank-conflict free (stride 144 B = 36 banks).
+#include <stdlib.h>
+
 #include "ops.h"
 
 static constexpr int BK = 64;
@@ -188,6 +190,211 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2: asynchronous LDS-DMA staging (global_load_lds_dwordx4), no staging registers, no ds_write pass.
+//   * each wave-level DMA instruction fills 1 KiB of LDS lane-linearly, so the bank-conflict-free layout is obtained by
+//     permuting the per-lane SOURCE address and applying the same involution on the fragment read:
+//       logical (row R, 16-byte chunk s)  ->  byte  (R>>4)*2048 + (R&7)*256 + ((R>>3)&1)*128 + ((s ^ (R&7)) * 16)
+//     (a ds_read_b128 lane group then touches 16 distinct 16-byte slots of the 256-byte bank row);
+//   * conv zero padding / M,N tails: out-of-range lanes read from a zeroed page instead of being masked (a masked DMA lane
+//     would leave stale LDS bytes);
+//   * two LDS stages (64 KiB at 128x128 -> two blocks per CU); the DMA of chunk k+1 flies under the MFMAs of chunk k and is
+//     drained by the vmcnt(0) the compiler puts in front of the one barrier per chunk.
+// Requires (C1 + C2) % 64 == 0 and C1 % 64 == 0 (every SD-1.x layer but the 4/3-channel stems, which stay on v1).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// ABL: 0 = product kernel; 1 = DMA only (no fragment reads / MFMA); 2 = compute only (no DMA) -- bottleneck ablations for tools/.
+template <int BM, int BN, int BKT, int NST, int ABL = 0>
+__global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
+  static_assert(BKT == 64 || BKT == 32, "BKT");
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  constexpr int RPI = 1024 / (BKT * 2);                // tile rows per 1-KiB DMA instruction (8 or 16)
+  constexpr int AV = BM / RPI / 4, WV = BN / RPI / 4;  // DMA instructions per wave per chunk and operand
+  constexpr int ROWB = BKT * 2;                        // bytes per tile row
+  constexpr int STAGE = (BM + BN) * ROWB;              // bytes
+  constexpr int T32 = 32 * ROWB;                       // bytes per 32-row MFMA tile
+  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int Cin = p.C1 + p.C2;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- DMA lane roles.  A wave-level DMA instruction fills 1 KiB lane-linearly; the (row, chunk) a lane fetches is the
+  // inverse of the swizzled LDS layout:
+  //   BKT = 64: 128-byte rows, byte(R, s) = (R>>4)*2048 + (R&7)*256 + ((R>>3)&1)*128 + ((s ^ (R&7)) * 16)
+  //   BKT = 32:  64-byte rows, byte(R, s) = (R>>4)*1024 + ((R>>2)&3)*256 + (R&3)*64 + ((s ^ ((R>>2)&3)) * 16)
+  // Everything of the gather that does not depend on the k-chunk is precomputed per row; the per-chunk address is pure
+  // arithmetic (no selects that could turn into divergent control flow, no runtime-indexed arrays -> no scratch).
+  int d_row, d_chunk;   // row within the instruction's row group, logical 16-byte chunk
+  if (BKT == 64) {
+    const int line_lo = lane >> 4, half = (lane >> 3) & 1;
+    d_row = half * 8 + line_lo;         // + 4 * (j & 1) added below
+    d_chunk = lane & 7;                 // ^ line below
+  } else {
+    d_row = (lane >> 4) * 4 + ((lane >> 2) & 3);
+    d_chunk = (lane & 3) ^ (lane >> 4);
+  }
+  int a_y0[AV], a_x0[AV], a_bh[AV], a_chunk[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int j = wave * AV + i;
+    int R, ch;
+    if (BKT == 64) { const int line = 4 * (j & 1) + (lane >> 4); R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line; ch = (lane & 7) ^ line; }
+    else { R = j * 16 + d_row; ch = d_chunk; }
+    a_chunk[i] = ch * 8;
+    const int m = m0 + R;
+    int b = m / HoWo;
+    int rr = m - b * HoWo;
+    int yo = rr / p.Wo;
+    int xo = rr - yo * p.Wo;
+    a_bh[i] = b * p.H;
+    a_y0[i] = m < p.M ? yo * p.stride - p.pad : -(1 << 20);   // rows past M fail the bounds test for every tap
+    a_x0[i] = xo * p.stride - p.pad;
+  }
+  const int lim_y = p.ups ? 2 * p.H : p.H, lim_x = p.ups ? 2 * p.W : p.W, ups_sh = p.ups ? 1 : 0;
+  const half_t* w_ptr[WV];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) {
+    const int j = wave * WV + i;
+    int R, ch;
+    if (BKT == 64) { const int line = 4 * (j & 1) + (lane >> 4); R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line; ch = (lane & 7) ^ line; }
+    else { R = j * 16 + d_row; ch = d_chunk; }
+    const int n = n0 + R;
+    w_ptr[i] = n < p.N ? p.w + (size_t)n * p.ldw + ch * 8 : zero_page;
+  }
+
+  const int nchunks = p.K / BKT;
+  int kc0 = 0, kc1 = nchunks;
+  if (p.splitk > 1) {   // kchunks_per_split is given in 64-wide chunks
+    kc0 = blockIdx.z * p.kchunks_per_split * (64 / BKT);
+    kc1 = min(nchunks, kc0 + p.kchunks_per_split * (64 / BKT));
+  }
+  // incremental (tap, channel) position of the next chunk to issue: wave-uniform scalars
+  int is_tap = (kc0 * BKT) / Cin;
+  int is_c0 = kc0 * BKT - is_tap * Cin;
+  int is_kk = kc0 * BKT;
+
+  auto issue = [&](int buf) {
+    char* sA = smem_raw + buf * STAGE;
+    char* sW = sA + BM * ROWB;
+    int r = 0, s = 0;
+    if (p.ksize == 3) { r = is_tap / 3; s = is_tap - 3 * r; }
+    const half_t* src; int ld, cc;
+    if (is_c0 < p.C1) { src = p.x1; ld = p.ldx1; cc = is_c0; } else { src = p.x2; ld = p.ldx2; cc = is_c0 - p.C1; }
+    const long zoff = zero_page - src;   // element distance to the zero page (plain integer arithmetic on addresses)
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int yi = a_y0[i] + r, xi = a_x0[i] + s;
+      const bool ok = (unsigned)yi < (unsigned)lim_y && (unsigned)xi < (unsigned)lim_x;
+      const long off = (long)((a_bh[i] + (yi >> ups_sh)) * p.W + (xi >> ups_sh)) * ld + (cc + a_chunk[i]);
+      const long mask = -(long)ok;                       // all ones when in range: select without control flow
+      const half_t* g = src + ((off & mask) | (zoff & ~mask));
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sA + (wave * AV + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const half_t* g = w_ptr[i] + (w_ptr[i] == zero_page ? 0 : is_kk);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sW + (wave * WV + i) * 1024), 16, 0, 0);
+    }
+    is_kk += BKT;
+    is_c0 += BKT;
+    if (is_c0 >= Cin) { is_c0 = 0; ++is_tap; }
+  };
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // fragment read addressing (same involution as the DMA source permutation)
+  const int lr = lane & 31, hk = lane >> 5;
+  int lane_row_off, xk;
+  if (BKT == 64) { lane_row_off = (lr >> 4) * 2048 + (lr & 7) * 256 + ((lr >> 3) & 1) * 128; xk = lr & 7; }
+  else { lane_row_off = (lr >> 4) * 1024 + ((lr >> 2) & 3) * 256 + (lr & 3) * 64; xk = (lr >> 2) & 3; }
+
+  // NST-deep LDS ring.  Chunk k+NST-1 is issued while chunk k is computed; each wave waits for ITS loads of chunk k with a
+  // counted vmcnt (the newer chunks stay in flight across the barrier), then one raw barrier per chunk makes every wave's
+  // part of chunk k visible and, at the same time, frees the stage that was read in the previous iteration.
+  constexpr int LPS = AV + WV;   // DMA instructions per wave per chunk
+  if (kc0 < kc1) {
+    const int total = kc1 - kc0;
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+      if (issued < total) { if (ABL != 2) issue(st); ++issued; }
+    int rd = 0, wr = NST - 1;
+    for (int it = 0; it < total; ++it) {
+      const int ahead = issued - it - 1;           // chunks issued after the one needed now (0 .. NST-2)
+      if (NST == 2 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      if (issued < total) { if (ABL != 2) issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
+      if (ABL == 1) { rd = rd + 1 == NST ? 0 : rd + 1; continue; }
+      const char* sA = smem_raw + rd * STAGE + (wm0 >> 5) * T32 + lane_row_off;
+      const char* sW = smem_raw + rd * STAGE + BM * ROWB + (wn0 >> 5) * T32 + lane_row_off;
+#pragma unroll
+      for (int kk = 0; kk < BKT / 16; ++kk) {
+        const int ko = ((kk * 2 + hk) ^ xk) * 16;
+        half8 wf[NI], af[MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const half8*>(sW + ni * T32 + ko);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8*>(sA + mi * T32 + ko);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(wf[ni], af[mi], acc[mi][ni]);
+      }
+      rd = rd + 1 == NST ? 0 : rd + 1;
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wm0 + mi * 32 + (lane & 31);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = n0 + wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+        float v[4] = {acc[mi][ni][4 * g + 0], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+        if (p.splitk > 1) {
+          if (m < p.M) {
+            float* dst = p.slab + ((size_t)blockIdx.z * p.M + m) * p.N + nb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (nb + j < p.N) dst[j] = v[j];
+          }
+        } else {
+          epilogue_store4(p, m, nb, v);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BKT, int NST, int ABL = 0>
+static int launch_dma(const GemmP& p, dim3 grid, hipStream_t st, const half_t* zero_page) {
+  constexpr int lds = NST * (BM + BN) * BKT * 2;
+  static bool attr = false;
+  if (!attr) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  igemm_dma_kernel<BM, BN, BKT, NST, ABL><<<grid, 256, lds, st>>>(p, zero_page);
+  return 0;
+}
+
 // Deterministic split-K combine: fixed slab order, then the common epilogue.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmP p) {
   const int groups_per_row = (p.N + 3) / 4;
@@ -216,7 +423,19 @@ void gemm_defaults(GemmP& p) {
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
 
+static half_t* g_zero_page = nullptr;
+static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
+static int g_var128 = 2, g_var64 = 0;   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
+void igemm_set_dma(int on) { g_use_dma = on; }
+
 int igemm_init() {
+  if (const char* e = getenv("PNPI_IGEMM_DMA")) g_use_dma = atoi(e);
+  if (const char* e = getenv("PNPI_IGEMM_V128")) g_var128 = atoi(e);
+  if (const char* e = getenv("PNPI_IGEMM_V64")) g_var64 = atoi(e);
+  if (!g_zero_page) {
+    HIP_CHECK_RET(hipMalloc((void**)&g_zero_page, 4096));
+    HIP_CHECK_RET(hipMemset(g_zero_page, 0, 4096));
+  }
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(128, 128)));
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(128, 128)));
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<64, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(64, 64)));
@@ -254,13 +473,37 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   p.slab = ws;
+  const bool dma = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
   if (cfg == 0) {
     dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, 1);
-    if (fast) igemm_kernel<128, 128, true><<<grid, 256, lds_bytes(128, 128), st>>>(p);
+    if (dma) {
+      int r;
+      switch (g_var128) {
+        case 1: r = launch_dma<128, 128, 64, 3>(p, grid, st, g_zero_page); break;
+        case 2: r = launch_dma<128, 128, 32, 3>(p, grid, st, g_zero_page); break;
+        case 3: r = launch_dma<128, 128, 32, 4>(p, grid, st, g_zero_page); break;
+        case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
+        case 11: r = launch_dma<128, 128, 32, 3, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
+        case 12: r = launch_dma<128, 128, 32, 3, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
+        default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;
+      }
+      if (r) return r;
+    }
+    else if (fast) igemm_kernel<128, 128, true><<<grid, 256, lds_bytes(128, 128), st>>>(p);
     else igemm_kernel<128, 128, false><<<grid, 256, lds_bytes(128, 128), st>>>(p);
   } else {
     dim3 grid((p.M + 63) / 64, (p.N + 63) / 64, split);
-    if (fast) igemm_kernel<64, 64, true><<<grid, 256, lds_bytes(64, 64), st>>>(p);
+    if (dma) {
+      int r;
+      switch (g_var64) {
+        case 1: r = launch_dma<64, 64, 64, 2>(p, grid, st, g_zero_page); break;
+        case 2: r = launch_dma<64, 64, 64, 4>(p, grid, st, g_zero_page); break;
+        case 3: r = launch_dma<64, 64, 32, 4>(p, grid, st, g_zero_page); break;
+        default: r = launch_dma<64, 64, 64, 3>(p, grid, st, g_zero_page); break;
+      }
+      if (r) return r;
+    }
+    else if (fast) igemm_kernel<64, 64, true><<<grid, 256, lds_bytes(64, 64), st>>>(p);
     else igemm_kernel<64, 64, false><<<grid, 256, lds_bytes(64, 64), st>>>(p);
     if (split > 1) {
       size_t total = (size_t)p.M * ((p.N + 3) / 4);

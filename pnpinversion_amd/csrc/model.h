@@ -132,7 +132,7 @@ struct CtrlDev {
   float* lb_acc = nullptr;        // [npairs][nslots][2][tokens]
 };
 
-struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; int M, N, K, ksize; };
 
 struct pnpi_ctx {
   pnpi_model_config cfg;

@@ -6,8 +6,11 @@
 #include "ops.h"
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
-// Pass 1: per (batch, pixel-chunk) partial sums per group. Each thread owns a fixed 8-channel vector and walks pixels;
-// the per-channel sums are reduced in a fixed order (deterministic, no atomics).
+// Three launches, all latency-lean:
+//   gn_stats    (B x nchunk blocks)  per-chunk partial (sum, sumsq) per group; each thread owns a fixed 8-channel vector and walks
+//                                    pixels four at a time (independent loads in flight); fixed-order reduction, no atomics
+//   gn_finalize (B blocks)           partials -> per-channel scale = rstd*gamma, shift = beta - mean*scale   ([B][C][2] fp32)
+//   gn_apply    (B x napply blocks)  y = x*scale + shift (+SiLU), 16-byte accesses
 __global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1,
                                                        int C2, int HW, int G, int nchunk, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -27,8 +30,22 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict_
       const int c = cv * 8;
       const half_t* src; int ld, cc;
       if (c < C1) { src = x1; ld = C1; cc = c; } else { src = x2; ld = C2; cc = c - C1; }
-      for (int pix = p0 + tp; pix < p1; pix += TP) {
-        half8 v = ldg_half8(src + ((size_t)b * HW + pix) * ld + cc);
+      const half_t* base = src + (size_t)b * HW * ld + cc;
+      int pix = p0 + tp;
+      for (; pix + 3 * TP < p1; pix += 4 * TP) {
+        half8 v0 = ldg_half8(base + (size_t)pix * ld);
+        half8 v1 = ldg_half8(base + (size_t)(pix + TP) * ld);
+        half8 v2 = ldg_half8(base + (size_t)(pix + 2 * TP) * ld);
+        half8 v3 = ldg_half8(base + (size_t)(pix + 3 * TP) * ld);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f0 = (float)v0[j], f1 = (float)v1[j], f2 = (float)v2[j], f3 = (float)v3[j];
+          s[j] += (f0 + f1) + (f2 + f3);
+          q[j] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        }
+      }
+      for (; pix < p1; pix += TP) {
+        half8 v = ldg_half8(base + (size_t)pix * ld);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
       }
@@ -54,54 +71,64 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const half_t* __restrict_
   }
 }
 
-// Pass 2: finalize the statistics (fixed chunk order), fold gamma/beta into per-channel scale/shift, stream the pixels.
-__global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1,
-                                                       int C2, int HW, int G, int nchunk, int napply, float eps,
-                                                       const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int silu, half_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int C = C1 + C2, C8 = C >> 3;
-  float* s_scale = reinterpret_cast<float*>(smem_raw);  // [C]
-  float* s_shift = s_scale + C;                          // [C]
-  float* s_mean = s_shift + C;                           // [G]
-  float* s_rstd = s_mean + G;                            // [G]
-  const int b = blockIdx.x;
+// One block per batch row: 8 lanes per group sum the chunk partials (fixed order), then scale/shift for every channel.
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int C, int HW, int G, int nchunk,
+                                                          float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ ss) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int g = g0 + (tid >> 3), sub = tid & 7;
     float s = 0.f, q = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float* src = partial + (((size_t)b * nchunk + ch) * G + g) * 2;
-      s += src[0];
-      q += src[1];
+    if (g < G)
+      for (int ch = sub; ch < nchunk; ch += 8) {
+        const float* src = partial + (((size_t)b * nchunk + ch) * G + g) * 2;
+        s += src[0];
+        q += src[1];
+      }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if (g < G && sub == 0) {
+      const float n = (float)HW * (float)cpg;
+      float mean = s / n;
+      float var = q / n - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      s_mean[g] = mean;
+      s_rstd[g] = rsqrtf(var + eps);
     }
-    const float n = (float)HW * (float)cpg;
-    float mean = s / n;
-    float var = q / n - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    s_mean[g] = mean;
-    s_rstd[g] = rsqrtf(var + eps);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int c = tid; c < C; c += blockDim.x) {
     int g = c / cpg;
     float sc = s_rstd[g] * gamma[c];
-    s_scale[c] = sc;
-    s_shift[c] = beta[c] - s_mean[g] * sc;
+    ss[((size_t)b * C + c) * 2 + 0] = sc;
+    ss[((size_t)b * C + c) * 2 + 1] = beta[c] - s_mean[g] * sc;
   }
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1,
+                                                       int C2, int HW, int napply, const float* __restrict__ ss, int silu,
+                                                       half_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int C = C1 + C2, C8 = C >> 3;
+  float* s_ss = reinterpret_cast<float*>(smem_raw);  // [C][2]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_ss[i] = ss[(size_t)b * C * 2 + i];
   __syncthreads();
   const int ppc = (HW + napply - 1) / napply;
   const int p0 = blockIdx.y * ppc, p1 = min(HW, p0 + ppc);
-  const size_t nvec = (size_t)(p1 > p0 ? p1 - p0 : 0) * C8;
-  for (size_t idx = threadIdx.x; idx < nvec; idx += blockDim.x) {
-    int pix = p0 + (int)(idx / C8);
-    int c = (int)(idx % C8) * 8;
+  const int nvec = (p1 > p0 ? p1 - p0 : 0) * C8;
+  for (int idx = threadIdx.x; idx < nvec; idx += blockDim.x) {
+    int pix = p0 + idx / C8;
+    int c = (idx % C8) * 8;
     const half_t* src; int ld, cc;
     if (c < C1) { src = x1; ld = C1; cc = c; } else { src = x2; ld = C2; cc = c - C1; }
     half8 v = ldg_half8(src + ((size_t)b * HW + pix) * ld + cc);
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float f = (float)v[j] * s_scale[c + j] + s_shift[c + j];
+      float f = (float)v[j] * s_ss[(c + j) * 2] + s_ss[(c + j) * 2 + 1];
       if (silu) f = silu_f(f);
       o[j] = (half_t)f;
     }
@@ -112,18 +139,20 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict_
 static int gn_nchunk(int HW) { int n = HW / 64; if (n < 1) n = 1; if (n > 128) n = 128; return n; }
 static int gn_napply(int HW) { int n = HW / 16; if (n < 1) n = 1; if (n > 1024) n = 1024; return n; }
 
+// partial: fp32 scratch of at least B * (nchunk * G * 2 + C * 2) floats
 int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                      const float* beta, int silu, half_t* out, float* partial, hipStream_t st) {
   const int C = C1 + C2;
-  if ((C & 7) || (C1 & 7) || C % G) return -3;
+  if ((C & 7) || (C1 & 7) || C % G || G > 64) return -3;
   const int C8 = C >> 3;
   const int TC = C8 < 256 ? C8 : 256, TP = 256 / TC;
   const int nchunk = gn_nchunk(HW);
+  float* ss = partial + (size_t)B * nchunk * G * 2;
   size_t lds1 = (size_t)TP * C * 2 * sizeof(float);
   gn_stats_kernel<<<dim3(B, nchunk), 256, lds1, st>>>(x1, x2, C1, C2, HW, G, nchunk, partial);
-  size_t lds2 = (size_t)(2 * C + 2 * G) * sizeof(float);
+  gn_finalize_kernel<<<B, 256, 0, st>>>(partial, C, HW, G, nchunk, eps, gamma, beta, ss);
   const int napply = gn_napply(HW);
-  gn_apply_kernel<<<dim3(B, napply), 256, lds2, st>>>(x1, x2, C1, C2, HW, G, nchunk, napply, eps, partial, gamma, beta, silu, out);
+  gn_apply_kernel<<<dim3(B, napply), 256, (size_t)2 * C * sizeof(float), st>>>(x1, x2, C1, C2, HW, napply, ss, silu, out);
   return (int)hipGetLastError();
 }
 
