@@ -173,6 +173,9 @@ int pnpi_op_conv(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16
 int pnpi_op_gemm(pnpi_ctx* ctx, const void* a_f16, int lda, const void* w_f16, int ldw, int M, int N, int K, float alpha,
                  const float* bias, const void* residual_f16, void* out_f16, int ldo, int vt_col0, void* outT,
                  int vt_ld, int vt_f32, int rows_per_batch, int force_cfg, int force_split);
+/* out[m][j] = x * gelu(gate) with the N = 2*I weight rows / bias packed as [x(32) | gate(32)] groups (fused GEGLU epilogue) */
+int pnpi_op_gemm_geglu(pnpi_ctx* ctx, const void* a_f16, int lda, const void* w_f16, int ldw, int M, int N, int K,
+                       const float* bias, void* out_f16, int ldo);
 int pnpi_op_groupnorm(pnpi_ctx* ctx, const void* x1, const void* x2, int C1, int C2, int B, int HW, int groups, float eps,
                       const float* gamma, const float* beta, int silu, void* out);
 int pnpi_op_layernorm(pnpi_ctx* ctx, const void* x, int M, int C, float eps, const float* gamma, const float* beta, void* out);

@@ -78,6 +78,7 @@ SYMBOLS = {
     "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _vp]),
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     "pnpi_op_gemm": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
+    "pnpi_op_gemm_geglu": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
     "pnpi_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "pnpi_op_layernorm": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "pnpi_op_geglu": (_i, [_vp, _vp, _i, _i, _vp]),

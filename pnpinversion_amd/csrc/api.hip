@@ -46,12 +46,12 @@ static int fail_launch(pnpi_ctx* c, int code, const char* what) {
 static void reg_mat(pnpi_ctx* c, const std::string& name, half_t* dst, int rows, int cols, int taps, int dst_ld, int cin_pad,
                     int row0 = 0, int dh = 0, int Dp = 0) {
   Slot s; s.kind = 0; s.dst = dst; s.rows = rows; s.cols = cols; s.taps = taps; s.dst_ld = dst_ld; s.cin_pad = cin_pad;
-  s.row0 = row0; s.dh = dh; s.Dp = Dp; s.n = 0; s.loaded = false;
+  s.row0 = row0; s.dh = dh; s.Dp = Dp; s.n = 0; s.ilv_half = 0; s.loaded = false;
   c->slots[name] = s;
 }
 static void reg_vec(pnpi_ctx* c, const std::string& name, float* dst, int n) {
   Slot s; s.kind = 1; s.dst = dst; s.rows = 0; s.cols = 0; s.taps = 0; s.dst_ld = 0; s.cin_pad = 0; s.row0 = 0; s.dh = 0; s.Dp = 0;
-  s.n = n; s.loaded = false;
+  s.n = n; s.ilv_half = 0; s.loaded = false;
   c->slots[name] = s;
 }
 static half_t* walloc_h(pnpi_ctx* c, size_t n) { return (half_t*)c->warena.alloc(n * sizeof(half_t)); }
@@ -122,6 +122,9 @@ static TransformerW make_transformer(pnpi_ctx* c, const std::string& pre, int C,
   reg_mat(c, tb + ".attn2.to_v.weight", t.w_kv2, C, X, 1, X, X, hd, t.dh, t.Dp);
   t.o2 = make_lin(c, tb + ".attn2.to_out.0", C, C);
   t.ff1 = make_lin(c, tb + ".ff.net.0.proj", C, 8 * C);
+  // GEGLU fused into this GEMM's epilogue: x rows and gate rows are interleaved in groups of 32 (attention.py:331-333)
+  c->slots[tb + ".ff.net.0.proj.weight"].ilv_half = 4 * C;
+  c->slots[tb + ".ff.net.0.proj.bias"].ilv_half = 4 * C;
   t.ff2 = make_lin(c, tb + ".ff.net.2", 4 * C, C);
   t.proj_out = make_conv(c, pre + ".proj_out", C, C, 1);
   return t;
@@ -324,11 +327,11 @@ static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int 
 
 static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const half_t* w, int ldw, int N, const float* bias,
                    const half_t* res, int ldres, half_t* out, int ldo, float alpha = 1.f, const VtOut* vt = nullptr,
-                   double alg_flops = -1.0) {
+                   double alg_flops = -1.0, int geglu = 0) {
   GemmP p; gemm_defaults(p);
   p.x1 = a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
   p.w = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = res; p.ldres = ldres; p.alpha = alpha;
-  p.out = out; p.ldo = ldo;
+  p.out = out; p.ldo = ldo; p.geglu = geglu;
   if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
   c->ctr.executed_gemm_flops += 2.0 * M * N * K;
   if (c->dry) return 0;
@@ -436,10 +439,16 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   // ---- GEGLU feed-forward
   half_t* n3 = talloc(c, (size_t)M * C);
   if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)C * 2.0, launch_layernorm(hs2, M, C, 1e-5f, t.ln3.g, t.ln3.b, n3, c->st));
-  half_t* f1 = talloc(c, (size_t)M * 8 * C);
-  CK(op_gemm(c, n3, C, M, C, t.ff1.w, C, 8 * C, t.ff1.b, nullptr, 0, f1, 8 * C));
   half_t* f2 = talloc(c, (size_t)M * 4 * C);
-  if (!c->dry) PROF(PNPI_KC_GEGLU, 0.0, 12.0 * M * (double)C * 2.0, launch_geglu(f1, M, 4 * C, f2, c->st));
+  if (C % 64 == 0) {
+    // ff1 GEMM with the GEGLU product in its epilogue: [M][8C] never exists in memory
+    CK(op_gemm(c, n3, C, M, C, t.ff1.w, C, 8 * C, t.ff1.b, nullptr, 0, f2, 4 * C, 1.f, nullptr, -1.0, 1));
+  } else {
+    // narrow test configurations: the interleaved projection is materialised and combined by a small kernel
+    half_t* f1 = talloc(c, (size_t)M * 8 * C);
+    CK(op_gemm(c, n3, C, M, C, t.ff1.w, C, 8 * C, t.ff1.b, nullptr, 0, f1, 8 * C));
+    if (!c->dry) PROF(PNPI_KC_GEGLU, 0.0, 12.0 * M * (double)C * 2.0, launch_geglu(f1, M, 4 * C, f2, c->st));
+  }
   half_t* hs3 = talloc(c, (size_t)M * C);
   CK(op_gemm(c, f2, 4 * C, M, 4 * C, t.ff2.w, 4 * C, C, t.ff2.b, hs2, C, hs3, C));
   CK(op_conv(c, hs3, C, nullptr, 0, B, H, W, t.proj_out, 1, 0, 0, t.proj_out.b, x, out, H, W));
@@ -900,10 +909,11 @@ int pnpi_load_weights(pnpi_ctx* c, const pnpi_named_tensor* ts, int n) {
     for (int d = 0; d < t.ndim; ++d) numel *= (size_t)t.shape[d];
     if (s.kind == 0) {
       if (numel != (size_t)s.rows * s.cols * s.taps) { c->err = "shape mismatch for " + name; return PNPI_ESHAPE; }
-      CK(launch_repack_matrix(t.data, t.dtype, s.rows, s.cols, s.taps, (half_t*)s.dst, s.dst_ld, s.cin_pad, s.row0, s.dh, s.Dp, c->st));
+      CK(launch_repack_matrix(t.data, t.dtype, s.rows, s.cols, s.taps, (half_t*)s.dst, s.dst_ld, s.cin_pad, s.row0, s.dh, s.Dp, c->st,
+                              s.ilv_half));
     } else {
       if (numel != (size_t)s.n) { c->err = "shape mismatch for " + name; return PNPI_ESHAPE; }
-      CK(launch_repack_vec(t.data, t.dtype, s.n, (float*)s.dst, c->st));
+      CK(launch_repack_vec(t.data, t.dtype, s.n, (float*)s.dst, c->st, s.ilv_half));
     }
     s.loaded = true;
   }
@@ -1214,6 +1224,14 @@ int pnpi_op_gemm(pnpi_ctx* c, const void* a, int lda, const void* w, int ldw, in
   p.ldres = N; p.out = (half_t*)out; p.ldo = ldo;
   if (outT) { p.outT = outT; p.vt_col0 = vt_col0; p.vt_ld = vt_ld; p.vt_f32 = vt_f32; p.rows_per_batch = rpb; }
   CK(launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, force_cfg, force_split));
+  return 0;
+}
+int pnpi_op_gemm_geglu(pnpi_ctx* c, const void* a, int lda, const void* w, int ldw, int M, int N, int K, const float* bias, void* out,
+                       int ldo) {
+  GemmP p; gemm_defaults(p);
+  p.x1 = (const half_t*)a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
+  p.w = (const half_t*)w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.out = (half_t*)out; p.ldo = ldo; p.geglu = 1;
+  CK(launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st));
   return 0;
 }
 int pnpi_op_groupnorm(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,

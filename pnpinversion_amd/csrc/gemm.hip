@@ -166,6 +166,78 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
   }
 
   // epilogue: accumulator register r of lane l is (n = tile_n + acc_row(r,l), m = tile_m + (l & 31))
+  if (p.epi_lds && p.splitk <= 1) {
+    // Coalesced epilogue: the output tile is assembled in LDS (the ring is idle now) and written as full rows, 16 bytes per
+    // lane.  The residual tile is staged the same way, so out = fp16(alpha*acc + bias + residual) with a single rounding.
+    constexpr int OLD = BN + 8;                         // halfs per staged row
+    constexpr int VPR = BN / 8;                         // 16-byte vectors per row
+    half_t* sOut = reinterpret_cast<half_t*>(smem_raw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.res) {
+      for (int idx = tid; idx < BM * VPR; idx += 256) {
+        const int r = idx / VPR, v = idx - r * VPR;
+        const int m = m0 + r, n = n0 + v * 8;
+        half8 val = (m < p.M && n < p.N) ? ldg_half8(p.res + (size_t)m * p.ldres + n) : zero_half8();
+        *reinterpret_cast<half8*>(sOut + r * OLD + v * 8) = val;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ml = wm0 + mi * 32 + (lane & 31);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+          const int n = n0 + nl;
+          half4* slot = reinterpret_cast<half4*>(sOut + ml * OLD + nl);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = acc[mi][ni][4 * g + j] * p.alpha;
+            if (p.bias && n + j < p.N) o[j] += p.bias[n + j];
+          }
+          if (p.res) {
+            half4 r4 = *slot;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+          }
+          half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+          *slot = h4;
+        }
+      }
+    }
+    __syncthreads();
+    if (!p.geglu) {
+      for (int idx = tid; idx < BM * VPR; idx += 256) {
+        const int r = idx / VPR, v = idx - r * VPR;
+        const int m = m0 + r, n = n0 + v * 8;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
+      }
+    } else {
+      // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
+      constexpr int VPO = BN / 16;
+      for (int idx = tid; idx < BM * VPO; idx += 256) {
+        const int r = idx / VPO, v = idx - r * VPO;
+        const int m = m0 + r;
+        const int xc = (v >> 2) * 64 + (v & 3) * 8;     // local column of the x vector; its gate sits 32 columns further
+        const int no = (n0 >> 1) + v * 8;
+        if (m < p.M && no < (p.N >> 1)) {
+          half8 x = *reinterpret_cast<const half8*>(sOut + r * OLD + xc);
+          half8 gt = *reinterpret_cast<const half8*>(sOut + r * OLD + xc + 32);
+          half8 o8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o8[j] = (half_t)((float)x[j] * gelu_f((float)gt[j]));
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + no) = o8;
+        }
+      }
+    }
+    return;
+  }
+
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm0 + mi * 32 + (lane & 31);
@@ -359,6 +431,78 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
     }
   }
 
+  if (p.epi_lds && p.splitk <= 1) {
+    // Coalesced epilogue: the output tile is assembled in LDS (the ring is idle now) and written as full rows, 16 bytes per
+    // lane.  The residual tile is staged the same way, so out = fp16(alpha*acc + bias + residual) with a single rounding.
+    constexpr int OLD = BN + 8;                         // halfs per staged row
+    constexpr int VPR = BN / 8;                         // 16-byte vectors per row
+    half_t* sOut = reinterpret_cast<half_t*>(smem_raw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.res) {
+      for (int idx = tid; idx < BM * VPR; idx += 256) {
+        const int r = idx / VPR, v = idx - r * VPR;
+        const int m = m0 + r, n = n0 + v * 8;
+        half8 val = (m < p.M && n < p.N) ? ldg_half8(p.res + (size_t)m * p.ldres + n) : zero_half8();
+        *reinterpret_cast<half8*>(sOut + r * OLD + v * 8) = val;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ml = wm0 + mi * 32 + (lane & 31);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+          const int n = n0 + nl;
+          half4* slot = reinterpret_cast<half4*>(sOut + ml * OLD + nl);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = acc[mi][ni][4 * g + j] * p.alpha;
+            if (p.bias && n + j < p.N) o[j] += p.bias[n + j];
+          }
+          if (p.res) {
+            half4 r4 = *slot;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+          }
+          half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+          *slot = h4;
+        }
+      }
+    }
+    __syncthreads();
+    if (!p.geglu) {
+      for (int idx = tid; idx < BM * VPR; idx += 256) {
+        const int r = idx / VPR, v = idx - r * VPR;
+        const int m = m0 + r, n = n0 + v * 8;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
+      }
+    } else {
+      // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
+      constexpr int VPO = BN / 16;
+      for (int idx = tid; idx < BM * VPO; idx += 256) {
+        const int r = idx / VPO, v = idx - r * VPO;
+        const int m = m0 + r;
+        const int xc = (v >> 2) * 64 + (v & 3) * 8;     // local column of the x vector; its gate sits 32 columns further
+        const int no = (n0 >> 1) + v * 8;
+        if (m < p.M && no < (p.N >> 1)) {
+          half8 x = *reinterpret_cast<const half8*>(sOut + r * OLD + xc);
+          half8 gt = *reinterpret_cast<const half8*>(sOut + r * OLD + xc + 32);
+          half8 o8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o8[j] = (half_t)((float)x[j] * gelu_f((float)gt[j]));
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + no) = o8;
+        }
+      }
+    }
+    return;
+  }
+
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm0 + mi * 32 + (lane & 31);
@@ -385,7 +529,8 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
 
 template <int BM, int BN, int BKT, int NST, int ABL = 0>
 static int launch_dma(const GemmP& p, dim3 grid, hipStream_t st, const half_t* zero_page) {
-  constexpr int lds = NST * (BM + BN) * BKT * 2;
+  constexpr int ring = NST * (BM + BN) * BKT * 2, epi = BM * (BN + 8) * 2;   // the LDS epilogue re-uses the ring
+  constexpr int lds = ring > epi ? ring : epi;
   static bool attr = false;
   if (!attr) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -418,7 +563,7 @@ void gemm_defaults(GemmP& p) {
   p.B = 1; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.ksize = 1; p.stride = 1; p.pad = 0; p.ups = 0;
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
   p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1;
-  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0;
+  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0;
 }
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
@@ -472,6 +617,8 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (cfg_used) *cfg_used = cfg == 0 ? 0 : (split > 1 ? 2 : 1);
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
+  p.epi_lds = (p.vt_col0 >= p.N) && (p.N % 8 == 0) && (p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
+  if (p.geglu && !(p.epi_lds && fast && g_use_dma && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   p.slab = ws;
   const bool dma = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
   if (cfg == 0) {

@@ -33,6 +33,7 @@ struct Slot {
   void* dst;
   int rows, cols, taps, dst_ld, cin_pad, row0, dh, Dp;
   int n;
+  int ilv_half;  // > 0: GEGLU x/gate row interleave (groups of 32)
   bool loaded;
 };
 

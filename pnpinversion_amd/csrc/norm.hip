@@ -218,8 +218,10 @@ __global__ void __launch_bounds__(256) geglu_kernel(const half_t* __restrict__ x
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     size_t m = idx / I8;
     int c = (int)(idx - m * I8) * 8;
-    half8 a = ldg_half8(x + m * 2 * I + c);
-    half8 g = ldg_half8(x + m * 2 * I + I + c);
+    // x / gate columns are interleaved in groups of 32 (same packing as the fused GEMM epilogue)
+    const int xc = (c >> 5) * 64 + (c & 31);
+    half8 a = ldg_half8(x + m * 2 * I + xc);
+    half8 g = ldg_half8(x + m * 2 * I + xc + 32);
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] * gelu_f((float)g[j]));
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(256) geglu_kernel(const half_t* __restrict__ x
   }
 }
 int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st) {
-  if (I & 7) return -3;
+  if (I & 31) return -3;
   size_t total = (size_t)M * (I >> 3);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -404,8 +406,12 @@ int launch_gather_rows_f32(const float* in, const int* rows, int nrows, size_t r
 // ------------------------------------------------------------------------------------------------ weight repack
 // src: PyTorch [rows][cols][taps] (conv [out][in][kh*kw] or linear [out][in], taps = 1)
 // dst: fp16 [row'][tap * cin_pad + c], row' = row0 + (dh ? (r / dh) * Dp + r % dh : r)   (attention heads padded to Dp)
+__device__ __forceinline__ int ilv_row(int r, int half) {
+  if (half <= 0) return r;
+  return r < half ? (r >> 5) * 64 + (r & 31) : ((r - half) >> 5) * 64 + 32 + ((r - half) & 31);
+}
 __global__ void repack_matrix_kernel(const void* __restrict__ src, int src_f16, int rows, int cols, int taps, half_t* __restrict__ dst,
-                                     int dst_ld, int cin_pad, int row0, int dh, int Dp) {
+                                     int dst_ld, int cin_pad, int row0, int dh, int Dp, int ilv_half) {
   const size_t total = (size_t)rows * cols * taps;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     int tap = (int)(idx % taps);
@@ -413,27 +419,27 @@ __global__ void repack_matrix_kernel(const void* __restrict__ src, int src_f16, 
     int c = (int)(rc % cols);
     int r = (int)(rc / cols);
     float v = src_f16 ? (float)((const half_t*)src)[idx] : ((const float*)src)[idx];
-    int rr = row0 + (dh > 0 ? (r / dh) * Dp + (r % dh) : r);
+    int rr = row0 + (dh > 0 ? (r / dh) * Dp + (r % dh) : ilv_row(r, ilv_half));
     dst[(size_t)rr * dst_ld + (size_t)tap * cin_pad + c] = (half_t)v;
   }
 }
 int launch_repack_matrix(const void* src, int src_f16, int rows, int cols, int taps, half_t* dst, int dst_ld, int cin_pad, int row0,
-                         int dh, int Dp, hipStream_t st) {
+                         int dh, int Dp, hipStream_t st, int ilv_half) {
   size_t total = (size_t)rows * cols * taps;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  repack_matrix_kernel<<<blocks, 256, 0, st>>>(src, src_f16, rows, cols, taps, dst, dst_ld, cin_pad, row0, dh, Dp);
+  repack_matrix_kernel<<<blocks, 256, 0, st>>>(src, src_f16, rows, cols, taps, dst, dst_ld, cin_pad, row0, dh, Dp, ilv_half);
   return (int)hipGetLastError();
 }
-__global__ void repack_vec_kernel(const void* __restrict__ src, int src_f16, int n, float* __restrict__ dst) {
+__global__ void repack_vec_kernel(const void* __restrict__ src, int src_f16, int n, float* __restrict__ dst, int ilv_half) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    dst[i] = src_f16 ? (float)((const half_t*)src)[i] : ((const float*)src)[i];
+    dst[ilv_row(i, ilv_half)] = src_f16 ? (float)((const half_t*)src)[i] : ((const float*)src)[i];
 }
-int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream_t st) {
+int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream_t st, int ilv_half) {
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  repack_vec_kernel<<<blocks, 256, 0, st>>>(src, src_f16, n, dst);
+  repack_vec_kernel<<<blocks, 256, 0, st>>>(src, src_f16, n, dst, ilv_half);
   return (int)hipGetLastError();
 }

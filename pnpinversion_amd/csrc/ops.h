@@ -23,6 +23,8 @@ struct GemmP {
   half_t* out; int ldo;
   void* outT; int vt_col0, vt_ld, vt_f32, rows_per_batch;
   float* slab; int splitk, kchunks_per_split;
+  int geglu;      // N columns are [x(32) | gate(32)] interleaved groups; output has N/2 columns: x * gelu(gate)
+  int epi_lds;    // set by launch_igemm: coalesced LDS-staged epilogue is applicable
 };
 void gemm_defaults(GemmP& p);
 // ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.
@@ -44,9 +46,10 @@ int launch_softmax_rows(half_t* x, int M, int N, int ld, hipStream_t st);       
 int launch_gemv(const float* x, int K, const half_t* W, int N, const float* bias, const float* bias2, int silu_in,
                 float* out, hipStream_t st);
 // weight repack (PyTorch layouts -> fp16 KRSC / head-padded rows, fp32 vectors)
+// ilv_half > 0: rows [0, ilv_half) and [ilv_half, 2*ilv_half) are interleaved in groups of 32 (GEGLU x / gate pairing)
 int launch_repack_matrix(const void* src, int src_f16, int rows, int cols, int taps, half_t* dst, int dst_ld, int cin_pad,
-                         int row0, int dh, int Dp, hipStream_t st);
-int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream_t st);
+                         int row0, int dh, int Dp, hipStream_t st, int ilv_half = 0);
+int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream_t st, int ilv_half = 0);
 int launch_nchw_f32_to_nhwc_f16(const float* in, int B, int C, int HW, int Cp, half_t* out, hipStream_t st);
 int launch_f32_to_f16(const float* in, size_t n, half_t* out, hipStream_t st);
 int launch_img_u8_to_nhwc(const uint8_t* img, int n, int HW, int Cp, half_t* out, hipStream_t st);

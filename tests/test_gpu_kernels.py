@@ -156,13 +156,37 @@ def test_layernorm(ctx, M, C):
     assert rel_err(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)) < 2e-3
 
 
+def ilv32(a, g):
+    """[.., I] x and gate -> [.., 2I] packed as [x(32) | gate(32)] groups (the layout of the fused GEGLU epilogue)."""
+    I = a.shape[-1]
+    return torch.stack([a.reshape(*a.shape[:-1], I // 32, 32), g.reshape(*g.shape[:-1], I // 32, 32)], dim=-2).reshape(*a.shape[:-1], 2 * I)
+
+
 def test_geglu(ctx):
     M, I = 333, 256
     x = h16(M, 2 * I, scale=2.0, seed=16)
-    out = torch.zeros(M, I, dtype=torch.half, device=DEV)
-    ctx.call("pnpi_op_geglu", ptr(x), M, I, ptr(out))
     a, g = x.float().chunk(2, dim=-1)
+    xi = ilv32(a, g).half().contiguous()
+    out = torch.zeros(M, I, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_geglu", ptr(xi), M, I, ptr(out))
     assert rel_err(out, a * F.gelu(g)) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,I", [(4096, 320, 1280), (1024, 640, 2560), (200, 1280, 5120), (64, 64, 64)])
+def test_gemm_fused_geglu(ctx, M, K, I):
+    """GEGLU.forward (my_diffusers/models/attention.py:331-333): proj -> chunk -> x * gelu(gate), fused into the GEMM epilogue."""
+    a = h16(M, K, seed=51)
+    w = h16(2 * I, K, scale=1.0 / math.sqrt(K), seed=52)
+    bias = torch.randn(2 * I, device=DEV)
+    wx, wg = w[:I], w[I:]
+    wi = ilv32(wx.t(), wg.t()).t().contiguous()            # interleave rows
+    bi = ilv32(bias[:I][None], bias[I:][None])[0].contiguous()
+    out = torch.zeros(M, I, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_gemm_geglu", ptr(a), K, ptr(wi), K, M, 2 * I, K, ptr(bi), ptr(out), I)
+    h = a.float() @ w.float().t() + bias
+    ref = h[:, :I] * F.gelu(h[:, I:])
+    # the projection is rounded to fp16 once before the product (as the unfused reference path in fp16 would)
+    assert rel_err(out, ref) < 3e-3, rel_err(out, ref)
 
 
 def test_softmax_rows(ctx):
