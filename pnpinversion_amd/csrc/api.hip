@@ -271,12 +271,13 @@ static void prof_close(pnpi_ctx* c, ProfRec& r, int cls, double flops, double by
   r.cls = cls; r.flops = flops; r.bytes = bytes; r.M = M; r.N = N; r.K = K; r.ksize = ks;
   c->prof.push_back(r);
 }
-#define PROF(cls, flops, bytes, expr)                         \
+#define PROF(cls, flops, bytes, expr) PROFD(cls, flops, bytes, 0, 0, 0, expr)
+#define PROFD(cls, flops, bytes, d0, d1, d2, expr)            \
   do {                                                        \
     if (c->prof_on && !c->dry) {                              \
       ProfRec _pr; prof_open(c, _pr);                         \
       int _r = (expr);                                        \
-      prof_close(c, _pr, (cls), (flops), (bytes));            \
+      prof_close(c, _pr, (cls), (flops), (bytes), (d0), (d1), (d2)); \
       if (_r) return fail_launch(c, _r, #expr);               \
     } else {                                                  \
       int _r = (expr);                                        \
@@ -291,7 +292,7 @@ static half_t* palloc(pnpi_ctx* c, size_t n) { return (half_t*)c->persist.alloc(
 static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, const NormW& nw, int G, float eps,
                  int silu, half_t* out) {
   if (c->dry) return 0;
-  PROF(PNPI_KC_GROUPNORM, 0.0, 3.0 * B * HW * (double)(C1 + C2) * 2.0,
+  PROFD(PNPI_KC_GROUPNORM, 0.0, 3.0 * B * HW * (double)(C1 + C2) * 2.0, B * HW, C1 + C2, 0,
        launch_groupnorm(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, c->gn_partial, c->st));
   return 0;
 }
@@ -395,7 +396,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
     a.rows = rep ? cd.rows_rep : cd.rows_id; a.nrows = B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
-    if (!c->dry) PROF(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, launch_attn_flash(a, c->st));
+    if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, N, N, t.Dp, launch_attn_flash(a, c->st));
   }
   half_t* hs1 = talloc(c, (size_t)M * C);
   CK(op_gemm(c, ao, C, M, C, t.o1.w, C, C, t.o1.b, hs, C, hs1, C));
@@ -418,7 +419,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     a.rows = edit ? cd.rows_plain : cd.rows_id; a.nrows = edit ? cd.n_plain : B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * 96 * t.Dp;
-    if (!c->dry) PROF(PNPI_KC_ATTN_FLASH, 4.0 * a.nrows * t.heads * (double)N * T * t.dh, 0.0, launch_attn_flash(a, c->st));
+    if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * a.nrows * t.heads * (double)N * T * t.dh, 0.0, N, T, t.Dp, launch_attn_flash(a, c->st));
     if (edit && !c->dry) {
       CrossEditP e; e.q = q2; e.ldq = hd; e.q_off = 0; e.k = k2; e.ldk = hd; e.k_off = 0; e.vt = vt2; e.ldv = ldv2;
       e.o = ao2; e.ldo = C; e.heads = t.heads; e.Nq = N; e.Nk = T; e.Dp = t.Dp; e.dh = t.dh; e.scale = scale;

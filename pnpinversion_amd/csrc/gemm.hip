@@ -601,20 +601,39 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   int cfg = force_cfg;
   int split = 1;
   if (cfg < 0) {
-    if (t128 >= 192) cfg = 0;
-    else if (t64 >= 160) cfg = 1;
-    else cfg = 2;
-  }
-  if (cfg == 2) {
+    // Tile / split-K selection by a small cost model (constants fitted to per-shape timings on MI355X):
+    //   time ~ flops / (rate(tile) * busy CUs * residency factor) + split-K reduction traffic.
+    // 128x128 tiles move half the operand bytes per FLOP of 64x64 tiles (the LDS-DMA path is the limiter), but need split-K
+    // on the low-resolution layers to put work on all 256 CUs.
+    double best = 1e30;
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int tile = 0; tile < 2; ++tile) {
+      const long tiles = tile == 0 ? t128 : t64;
+      const double rate = tile == 0 ? 720e12 : 460e12;
+      const double flops = 2.0 * (double)tiles * (tile == 0 ? 128.0 * 128.0 : 64.0 * 64.0) * p.K;   // padded tiles do real work
+      for (int s : splits) {
+        if (s > 1 && (nchunks / s < 6 || (size_t)s * p.M * p.N * sizeof(float) > ws_bytes || ws == nullptr)) continue;
+        if (s > 1 && p.geglu) continue;
+        const double blocks = (double)tiles * s;
+        const double per_cu = blocks / 256.0;
+        const double busy = per_cu < 1.0 ? per_cu : 1.0;
+        const double resid = per_cu < 1.0 ? 0.55 : (per_cu < 2.0 ? 0.55 + 0.30 * (per_cu - 1.0) : (per_cu < 3.0 ? 0.85 + 0.15 * (per_cu - 2.0) : 1.0));
+        double t = flops / (rate * busy * resid);
+        if (s > 1) t += (double)(2 * s + 1) * p.M * p.N * 4.0 / 2.5e12 + 4e-6;   // slabs written, re-read, output
+        if (t < best) { best = t; cfg = tile == 0 ? 0 : (s > 1 ? 2 : 1); split = s; }
+      }
+    }
+  } else if (cfg == 2) {
     split = force_split > 0 ? force_split : (int)((512 + t64 - 1) / t64);
     if (split > 16) split = 16;
     if (split > nchunks) split = nchunks;
-    // every slice must own at least 4 k-chunks, otherwise the reduction traffic dominates
     while (split > 1 && nchunks / split < 4) --split;
     size_t need = (size_t)split * p.M * p.N * sizeof(float);
     if (split > 1 && (ws == nullptr || need > ws_bytes)) split = 1;
+  } else if (cfg == 0 && force_split > 1) {
+    split = force_split;
   }
-  if (cfg_used) *cfg_used = cfg == 0 ? 0 : (split > 1 ? 2 : 1);
+  if (cfg_used) *cfg_used = split > 1 ? 2 : (cfg == 0 ? 0 : 1);
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   p.epi_lds = (p.vt_col0 >= p.N) && (p.N % 8 == 0) && (p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
@@ -622,7 +641,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.slab = ws;
   const bool dma = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
   if (cfg == 0) {
-    dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, 1);
+    dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, split);
     if (dma) {
       int r;
       switch (g_var128) {
@@ -652,12 +671,12 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     }
     else if (fast) igemm_kernel<64, 64, true><<<grid, 256, lds_bytes(64, 64), st>>>(p);
     else igemm_kernel<64, 64, false><<<grid, 256, lds_bytes(64, 64), st>>>(p);
-    if (split > 1) {
-      size_t total = (size_t)p.M * ((p.N + 3) / 4);
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      splitk_reduce_kernel<<<blocks, 256, 0, st>>>(p);
-    }
+  }
+  if (split > 1) {
+    size_t total = (size_t)p.M * ((p.N + 3) / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    splitk_reduce_kernel<<<blocks, 256, 0, st>>>(p);
   }
   return (int)hipGetLastError();
 }

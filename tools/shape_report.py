@@ -2,7 +2,7 @@ import csv, collections, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.OrderedDict()
 for r in rows:
-    if int(r['cls'])>2: continue
+    if (int(r['cls'])>2) != (len(sys.argv)>2): continue
     k=(int(r['cls']),int(r['M']),int(r['N']),int(r['K']),int(r['ksize']))
     a=agg.setdefault(k,[0,0.0,0.0]); a[0]+=1; a[1]+=float(r['us']); a[2]+=float(r['flops'])
 tot=sum(v[1] for v in agg.values())
