@@ -14,6 +14,8 @@
 // Score matrices are never materialised (the reference materialises [B*8, N, N] fp32: 2.1 GB at 64x64).
 // Self-attention replacement ("tgt probabilities := src probabilities", attention_control.py:258-263) costs nothing here:
 // the target row simply takes Q and K from the source row (rows[] indirection) and keeps its own V.
+#include <stdlib.h>
+
 #include "ops.h"
 
 static constexpr int KV_TILE = 64;
@@ -88,35 +90,48 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
         s[st] = mfma32(kf, qf[ks], s[st]);
       }
     }
-    float mloc = -INFINITY;
+    // Only the last key tile can hold out-of-range keys: the mask is a wave-uniform branch, not per-tile VALU work.
+    if (kv0 + KV_TILE > p.Nk) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + st * 32 + acc_row(r, lane) >= p.Nk) s[st][r] = -INFINITY;
+    }
+    float mloc = s[0][0];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int key = kv0 + st * 32 + acc_row(r, lane);
-        float v = key < p.Nk ? s[st][r] : -INFINITY;
-        s[st][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[st][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float mnew = fmaxf(mrun, mloc);
-    const float alpha = exp2f((mrun - mnew) * c);
+    // Deferred rescale (flash-attention style): the running reference max only moves when some row's tile max exceeds it by
+    // more than 8 in the exp2 domain, so P <= 2^8 (fp16 has the range) and O / l are rescaled on few tiles only.  The
+    // decision precedes this tile's exponentials and every earlier P.V is already in O, so all terms share one scale.
+    const bool grow = (mloc - mrun) * c > 8.0f;
+    if (__any(grow)) {
+      const float mnew = fmaxf(mrun, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);   // mrun = -inf on the first tile -> 0
+      lrun *= alpha;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ot][r] *= alpha;
+      mrun = mnew;
+    }
+    const float mc = mrun * c;
     float psum = 0.f;
     half8 pf[2][2];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pv = exp2f((s[st][r] - mnew) * c);
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], c, -mc));
         psum += pv;
         pf[st][r >> 3][r & 7] = (half_t)pv;
       }
-    lrun = lrun * alpha + psum;
-    mrun = mnew;
+    lrun += psum;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[ot][r] *= alpha;
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -151,10 +166,163 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Self-attention fast path for the 64-wide (padded d = 40) heads with Nk % 64 == 0 -- the 4096-token layers that dominate
+// attention time.  Same math as attn_flash_kernel<64>; K / V^T tiles are staged by asynchronous LDS-DMA into a two-stage
+// ring with the XOR-swizzled 128-byte-row layout of gemm.hip (byte(R, s) = (R>>4)*2048 + (R&7)*256 + ((R>>3)&1)*128 +
+// ((s ^ (R&7))*16)), so the next tile flies under the current tile's MFMAs and no staging VGPRs / ds_writes are spent.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
+  constexpr int DP = 64, KS = 4, OT = 2;
+  constexpr int STAGE = 2 * 64 * 128;   // K tile + V^T tile, bytes
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ql = lane & 31;
+  const int head = blockIdx.y;
+  const int* rw = p.rows + blockIdx.z * 4;
+  const int orow = rw[0], qrow = rw[1], krow = rw[2], vrow = rw[3];
+  const int qtok = blockIdx.x * 128 + wave * 32 + ql;
+  const bool qok = qtok < p.Nq;
+
+  half8 qf[KS];
+  {
+    const half_t* qp = p.q + ((size_t)qrow * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
+  }
+  floatx16 O[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[ot][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;
+
+  // DMA lane roles: instruction j (1 KiB = 8 rows) of a 64-row tile; this wave issues j = 2*wave, 2*wave+1 for K and for V^T
+  const half_t* kptr[2];
+  const half_t* vptr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave * 2 + i;
+    const int line = 4 * (j & 1) + (lane >> 4);
+    const int R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line;
+    const int ch = (lane & 7) ^ line;
+    kptr[i] = p.k + ((size_t)krow * p.Nk + R) * p.ldk + p.k_off + head * DP + ch * 8;            // + kv0 * ldk per tile
+    vptr[i] = p.vt + (((size_t)vrow * p.heads + head) * DP + R) * (size_t)p.ldv + ch * 8;        // + kv0 per tile
+  }
+  auto issue = [&](int buf, int kv0) {
+    char* sK = smem + buf * STAGE;
+    char* sV = sK + 64 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kptr[i] + (size_t)kv0 * p.ldk), (lds_ptr_t)(sK + (wave * 2 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vptr[i] + kv0), (lds_ptr_t)(sV + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+  };
+  const int x7 = ql & 7;
+  const int lane_row_off = (ql >> 4) * 2048 + (ql & 7) * 256 + ((ql >> 3) & 1) * 128;
+
+  const int ntiles = p.Nk / 64;
+  issue(0, 0);
+  for (int it = 0; it < ntiles; ++it) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < ntiles) issue(buf ^ 1, (it + 1) * 64);
+    const char* sK = smem + buf * STAGE + lane_row_off;
+    const char* sV = sK + 64 * 128;
+
+    floatx16 s[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half8 kf = *reinterpret_cast<const half8*>(sK + st * 4096 + (((ks * 2 + h) ^ x7) * 16));
+        s[st] = mfma32(kf, qf[ks], s[st]);
+      }
+    }
+    float mloc = s[0][0];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[st][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const bool grow = (mloc - mrun) * c > 8.0f;     // deferred rescale, see attn_flash_kernel
+    if (__any(grow)) {
+      const float mnew = fmaxf(mrun, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
+      lrun *= alpha;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ot][r] *= alpha;
+      mrun = mnew;
+    }
+    const float mc = mrun * c;
+    float psum = 0.f;
+    half8 pf[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], c, -mc));
+        psum += pv;
+        pf[st][r >> 3][r & 7] = (half_t)pv;
+      }
+    lrun += psum;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          // keys st*32 + t*16 + 4h + [0,4) and + 8: 16-byte chunks 4*st + 2*t and + 1 of row d, sub-offset 8h bytes
+          const int c0 = st * 4 + t * 2;
+          half4 lo = *reinterpret_cast<const half4*>(sV + ot * 4096 + ((c0 ^ x7) * 16) + 8 * h);
+          half4 hi = *reinterpret_cast<const half4*>(sV + ot * 4096 + (((c0 + 1) ^ x7) * 16) + 8 * h);
+          half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          O[ot] = mfma32(vf, pf[st][t], O[ot]);
+        }
+    }
+  }
+  const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+  const float inv = 1.f / ltot;
+  if (qok) {
+    half_t* op = p.o + ((size_t)orow * p.Nq + qtok) * p.ldo + head * p.dh;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int d = ot * 32 + 8 * g + 4 * h;
+        if (d + 3 < p.dh) {
+          half4 o4 = {(half_t)(O[ot][4 * g] * inv), (half_t)(O[ot][4 * g + 1] * inv), (half_t)(O[ot][4 * g + 2] * inv),
+                      (half_t)(O[ot][4 * g + 3] * inv)};
+          *reinterpret_cast<half4*>(op + d) = o4;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (d + j < p.dh) op[d + j] = (half_t)(O[ot][4 * g + j] * inv);
+        }
+      }
+  }
+}
+
 int launch_attn_flash(const AttnP& p, hipStream_t st) {
   if (p.nrows <= 0) return 0;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.q_off & 7) || (p.k_off & 7) || (p.dh & 3) || (p.ldo & 3)) return -3;
   dim3 grid((p.Nq + 127) / 128, p.heads, p.nrows);
+  static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
+  if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma) {
+    attn_flash_dma64_kernel<<<grid, 256, 0, st>>>(p);
+    return (int)hipGetLastError();
+  }
   switch (p.Dp) {
     case 32: attn_flash_kernel<32><<<grid, 256, 0, st>>>(p); break;
     case 64: attn_flash_kernel<64><<<grid, 256, 0, st>>>(p); break;
