@@ -286,12 +286,27 @@ static void prof_close(pnpi_ctx* c, ProfRec& r, int cls, double flops, double by
   } while (0)
 
 // ---------------------------------------------------------------------------------------------------- op wrappers
+// Per-channel GroupNorm partial sums attached to an activation by the GEMM that produced it ([tiles][C][2], `rows` per tile).
+struct Stats { const float* p = nullptr; int rows = 0; };
+struct StatsReq { float* buf = nullptr; int rows = 0; };   // in: buffer; out: rows per tile actually produced (0 = none)
+
 static half_t* talloc(pnpi_ctx* c, size_t n) { return (half_t*)c->temp.alloc(n * sizeof(half_t)); }
 static half_t* palloc(pnpi_ctx* c, size_t n) { return (half_t*)c->persist.alloc(n * sizeof(half_t)); }
 
 static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, const NormW& nw, int G, float eps,
-                 int silu, half_t* out) {
+                 int silu, half_t* out, Stats s1 = Stats(), Stats s2 = Stats()) {
   if (c->dry) return 0;
+  const bool ok1 = s1.p && s1.rows > 0 && HW % s1.rows == 0 && HW / s1.rows <= 256;
+  const bool ok2 = !x2 || (s2.p && s2.rows > 0 && HW % s2.rows == 0 && HW / s2.rows <= 256);
+  if (getenv("PNPI_GN_DEBUG"))
+    fprintf(stderr, "gn C=%d+%d HW=%d s1=(%p,%d) s2=(%p,%d) fused=%d\n", C1, C2, HW, (const void*)s1.p, s1.rows, (const void*)s2.p, s2.rows,
+            (int)(ok1 && ok2));
+  if (ok1 && ok2 && !getenv("PNPI_GN_NOFUSE")) {
+    PROFD(PNPI_KC_GROUPNORM, 0.0, 2.0 * B * HW * (double)(C1 + C2) * 2.0, B * HW, C1 + C2, 1,
+          launch_groupnorm_fused(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, s1.p, HW / s1.rows, s2.p,
+                                 x2 ? HW / s2.rows : 1, c->gn_partial, c->st));
+    return 0;
+  }
   PROFD(PNPI_KC_GROUPNORM, 0.0, 3.0 * B * HW * (double)(C1 + C2) * 2.0, B * HW, C1 + C2, 0,
        launch_groupnorm(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, c->gn_partial, c->st));
   return 0;
@@ -299,20 +314,27 @@ static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2
 
 struct VtOut { void* outT = nullptr; int col0 = 1 << 30; int ld = 0; int f32 = 0; int rpb = 1; };
 
-static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops) {
+
+static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops, StatsReq* sr = nullptr) {
+  int srows = 0, r;
   if (c->prof_on) {
     ProfRec pr; prof_open(c, pr);
     int used = 0;
-    int r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, &used);
+    r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, &used, &srows);
     prof_close(c, pr, used, alg_flops, 0.0, p.M, p.N, p.K, p.ksize);
-    return r;
+  } else {
+    r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, nullptr, &srows);
   }
-  return launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st);
+  if (sr) sr->rows = srows;
+  return r;
+}
+static float* stats_alloc(pnpi_ctx* c, int M, int N) {   // worst case: 64-row tiles
+  return (float*)c->persist.alloc((size_t)((M + 63) / 64) * N * 2 * sizeof(float));
 }
 
 static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int C2, int B, int H, int W, const ConvW& w, int stride,
                    int pad, int ups, const float* bias, const half_t* res, half_t* out, int Ho, int Wo, int N = -1,
-                   const VtOut* vt = nullptr) {
+                   const VtOut* vt = nullptr, StatsReq* sr = nullptr) {
   GemmP p; gemm_defaults(p);
   int C1p = C2 ? C1 : w.cin_pad;  // single-source inputs are stored with the padded channel count
   p.x1 = x1; p.x2 = x2; p.C1 = C1p; p.C2 = C2; p.ldx1 = C1p; p.ldx2 = C2;
@@ -322,8 +344,9 @@ static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int 
   p.bias = bias; p.res = res; p.ldres = p.N; p.out = out; p.ldo = p.N;
   if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
   c->ctr.executed_gemm_flops += 2.0 * p.M * p.N * p.K;
+  if (sr) { sr->buf = stats_alloc(c, p.M, p.N); sr->rows = 0; p.stats = sr->buf; }
   if (c->dry) return 0;
-  return igemm_prof(c, p, 2.0 * p.M * (double)w.cout * w.k * w.k * w.cin);
+  return igemm_prof(c, p, 2.0 * p.M * (double)w.cout * w.k * w.k * w.cin, sr);
 }
 
 static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const half_t* w, int ldw, int N, const float* bias,
@@ -341,24 +364,27 @@ static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const ha
 
 // ResnetBlock2D.forward (my_diffusers/models/resnet.py:331-365); x2 = skip tensor concatenated on the channel axis
 static int resnet_fwd(pnpi_ctx* c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, int B, int H, int W, int G,
-                      float eps, half_t* out) {
+                      float eps, half_t* out, Stats s1 = Stats(), Stats s2 = Stats(), Stats* so = nullptr) {
   const size_t mk = c->temp.mark();
   const int HW = H * W;
   const size_t M = (size_t)B * HW;
   half_t* t1 = talloc(c, M * r.cin);
-  CK(op_gn(c, x1, x2, C1, C2, B, HW, r.n1, G, eps, 1, t1));
+  CK(op_gn(c, x1, x2, C1, C2, B, HW, r.n1, G, eps, 1, t1, s1, s2));
   half_t* t2 = talloc(c, M * r.cout);
   const float* b1 = r.temb_off >= 0 ? c->bias_eff + r.temb_off : r.c1.b;
-  CK(op_conv(c, t1, r.cin, nullptr, 0, B, H, W, r.c1, 1, 1, 0, b1, nullptr, t2, H, W));
+  StatsReq q1, q2;
+  CK(op_conv(c, t1, r.cin, nullptr, 0, B, H, W, r.c1, 1, 1, 0, b1, nullptr, t2, H, W, -1, nullptr, &q1));
   half_t* t3 = talloc(c, M * r.cout);
-  CK(op_gn(c, t2, nullptr, r.cout, 0, B, HW, r.n2, G, eps, 1, t3));
+  Stats st2; st2.p = q1.buf; st2.rows = q1.rows;
+  CK(op_gn(c, t2, nullptr, r.cout, 0, B, HW, r.n2, G, eps, 1, t3, st2));
   const half_t* sc = x1;
   if (r.has_sc) {
     half_t* s = talloc(c, M * r.cout);
     CK(op_conv(c, x1, C1, x2, C2, B, H, W, r.sc, 1, 0, 0, r.sc.b, nullptr, s, H, W));
     sc = s;
   }
-  CK(op_conv(c, t3, r.cout, nullptr, 0, B, H, W, r.c2, 1, 1, 0, r.c2.b, sc, out, H, W));
+  CK(op_conv(c, t3, r.cout, nullptr, 0, B, H, W, r.c2, 1, 1, 0, r.c2.b, sc, out, H, W, -1, nullptr, &q2));
+  if (so) { so->p = q2.buf; so->rows = q2.rows; }
   c->temp.release(mk);
   return 0;
 }
@@ -366,7 +392,7 @@ static int resnet_fwd(pnpi_ctx* c, const ResnetW& r, const half_t* x1, int C1, c
 // SpatialTransformer + BasicTransformerBlock (my_diffusers/models/attention.py:140-200) with the hooked attention of
 // models/p2p/attention_control.py:20-47 and the controller semantics of :178-190, :269-282 fused into the kernels.
 static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, int B, int H, int W, const half_t* ctx16,
-                           bool use_ctrl, int cur_step, half_t* out) {
+                           bool use_ctrl, int cur_step, half_t* out, Stats sx = Stats(), Stats* so = nullptr) {
   const pnpi_model_config& g = c->cfg;
   const size_t mk = c->temp.mark();
   const int C = t.C, N = H * W, M = B * N, hd = t.heads * t.Dp, X = g.cross_dim, T = g.ctx_len;
@@ -375,7 +401,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   const bool edit = use_ctrl && cd.any_edit;
 
   half_t* g0 = talloc(c, (size_t)M * C);
-  CK(op_gn(c, x, nullptr, C, 0, B, N, t.gn, g.norm_groups, 1e-6f, 0, g0));
+  CK(op_gn(c, x, nullptr, C, 0, B, N, t.gn, g.norm_groups, 1e-6f, 0, g0, sx));
   half_t* hs = talloc(c, (size_t)M * C);
   CK(op_conv(c, g0, C, nullptr, 0, B, H, W, t.proj_in, 1, 0, 0, t.proj_in.b, nullptr, hs, H, W));
 
@@ -452,7 +478,9 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   }
   half_t* hs3 = talloc(c, (size_t)M * C);
   CK(op_gemm(c, f2, 4 * C, M, 4 * C, t.ff2.w, 4 * C, C, t.ff2.b, hs2, C, hs3, C));
-  CK(op_conv(c, hs3, C, nullptr, 0, B, H, W, t.proj_out, 1, 0, 0, t.proj_out.b, x, out, H, W));
+  StatsReq qo;
+  CK(op_conv(c, hs3, C, nullptr, 0, B, H, W, t.proj_out, 1, 0, 0, t.proj_out.b, x, out, H, W, -1, nullptr, &qo));
+  if (so) { so->p = qo.buf; so->rows = qo.rows; }
   c->temp.release(mk);
   return 0;
 }
@@ -477,65 +505,75 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
     CK(launch_gemv(c->temb_h, TE, u.t2.w, TE, u.t2.b, nullptr, 1, c->temb_emb, c->st));
     CK(launch_gemv(c->temb_emb, TE, u.temb_w, u.temb_total, u.temb_b, u.conv1_b, 1, c->bias_eff, c->st));
   }
-  struct Act { half_t* p; int C, H; };
+  struct Act { half_t* p; int C, H; Stats s; };
   std::vector<Act> skips;
   int H = S;
   half_t* h = palloc(c, (size_t)B * H * H * C0);
-  CK(op_conv(c, x0, 8, nullptr, 0, B, H, H, u.conv_in, 1, 1, 0, u.conv_in.b, nullptr, h, H, H));
+  Stats hs_;   // GroupNorm partial sums travelling with h
+  {
+    StatsReq q;
+    CK(op_conv(c, x0, 8, nullptr, 0, B, H, H, u.conv_in, 1, 1, 0, u.conv_in.b, nullptr, h, H, H, -1, nullptr, &q));
+    hs_.p = q.buf; hs_.rows = q.rows;
+  }
   int ch = C0;
-  skips.push_back({h, ch, H});
+  skips.push_back({h, ch, H, hs_});
   for (int i = 0; i < n; ++i) {
     const int oc = g.block_out_channels[i];
     for (int j = 0; j < g.layers_per_block; ++j) {
       half_t* o = palloc(c, (size_t)B * H * H * oc);
-      CKP(resnet_fwd(c, u.down_res[i][j], h, ch, nullptr, 0, B, H, H, G, eps, o));
-      h = o; ch = oc;
+      Stats ns;
+      CKP(resnet_fwd(c, u.down_res[i][j], h, ch, nullptr, 0, B, H, H, G, eps, o, hs_, Stats(), &ns));
+      h = o; ch = oc; hs_ = ns;
       if (g.block_has_attn[i]) {
         half_t* o2 = palloc(c, (size_t)B * H * H * oc);
-        CKP(transformer_fwd(c, u.down_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2));
-        h = o2;
+        CKP(transformer_fwd(c, u.down_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
+        h = o2; hs_ = ns;
       }
-      skips.push_back({h, ch, H});
+      skips.push_back({h, ch, H, hs_});
     }
     if (i != n - 1) {
       const int Ho = H / 2;
       half_t* o = palloc(c, (size_t)B * Ho * Ho * oc);
-      CK(op_conv(c, h, ch, nullptr, 0, B, H, H, u.down_samp[i], 2, 1, 0, u.down_samp[i].b, nullptr, o, Ho, Ho));
-      h = o; H = Ho;
-      skips.push_back({h, ch, H});
+      StatsReq q;
+      CK(op_conv(c, h, ch, nullptr, 0, B, H, H, u.down_samp[i], 2, 1, 0, u.down_samp[i].b, nullptr, o, Ho, Ho, -1, nullptr, &q));
+      h = o; H = Ho; hs_.p = q.buf; hs_.rows = q.rows;
+      skips.push_back({h, ch, H, hs_});
     }
   }
   {
     half_t* o = palloc(c, (size_t)B * H * H * ch);
-    CKP(resnet_fwd(c, u.mid_res[0], h, ch, nullptr, 0, B, H, H, G, eps, o));
+    Stats n1, n2, n3;
+    CKP(resnet_fwd(c, u.mid_res[0], h, ch, nullptr, 0, B, H, H, G, eps, o, hs_, Stats(), &n1));
     half_t* o2 = palloc(c, (size_t)B * H * H * ch);
-    CKP(transformer_fwd(c, u.mid_attn, o, B, H, H, ctx16, use_ctrl, cur_step, o2));
+    CKP(transformer_fwd(c, u.mid_attn, o, B, H, H, ctx16, use_ctrl, cur_step, o2, n1, &n2));
     half_t* o3 = palloc(c, (size_t)B * H * H * ch);
-    CKP(resnet_fwd(c, u.mid_res[1], o2, ch, nullptr, 0, B, H, H, G, eps, o3));
-    h = o3;
+    CKP(resnet_fwd(c, u.mid_res[1], o2, ch, nullptr, 0, B, H, H, G, eps, o3, n2, Stats(), &n3));
+    h = o3; hs_ = n3;
   }
   for (int i = 0; i < n; ++i) {
     const int oc = g.block_out_channels[n - 1 - i];
     for (int j = 0; j <= g.layers_per_block; ++j) {
       Act s = skips.back(); skips.pop_back();
       half_t* o = palloc(c, (size_t)B * H * H * oc);
-      CKP(resnet_fwd(c, u.up_res[i][j], h, ch, s.p, s.C, B, H, H, G, eps, o));
-      h = o; ch = oc;
+      Stats ns;
+      CKP(resnet_fwd(c, u.up_res[i][j], h, ch, s.p, s.C, B, H, H, G, eps, o, hs_, s.s, &ns));
+      h = o; ch = oc; hs_ = ns;
       if (g.block_has_attn[n - 1 - i]) {
         half_t* o2 = palloc(c, (size_t)B * H * H * oc);
-        CKP(transformer_fwd(c, u.up_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2));
-        h = o2;
+        CKP(transformer_fwd(c, u.up_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
+        h = o2; hs_ = ns;
       }
     }
     if (i != n - 1) {
       const int Ho = H * 2;
       half_t* o = palloc(c, (size_t)B * Ho * Ho * oc);
-      CK(op_conv(c, h, ch, nullptr, 0, B, H, H, u.up_samp[i], 1, 1, 1, u.up_samp[i].b, nullptr, o, Ho, Ho));
-      h = o; H = Ho;
+      StatsReq q;
+      CK(op_conv(c, h, ch, nullptr, 0, B, H, H, u.up_samp[i], 1, 1, 1, u.up_samp[i].b, nullptr, o, Ho, Ho, -1, nullptr, &q));
+      h = o; H = Ho; hs_.p = q.buf; hs_.rows = q.rows;
     }
   }
   half_t* gno = palloc(c, (size_t)B * H * H * ch);
-  CK(op_gn(c, h, nullptr, ch, 0, B, H * H, u.norm_out, G, eps, 1, gno));
+  CK(op_gn(c, h, nullptr, ch, 0, B, H * H, u.norm_out, G, eps, 1, gno, hs_));
   {
     VtOut v; v.outT = eps_out; v.col0 = 0; v.ld = H * H; v.f32 = 1; v.rpb = H * H;
     CK(op_conv(c, gno, ch, nullptr, 0, B, H, H, u.conv_out, 1, 1, 0, u.conv_out.b, nullptr, nullptr, H, H, -1, &v));

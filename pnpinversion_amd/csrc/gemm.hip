@@ -211,11 +211,48 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
     }
     __syncthreads();
     if (!p.geglu) {
+      // thread t owns the fixed 8-channel vector v = t % VPR and walks rows: per-channel sums for the GroupNorm that
+      // consumes this tensor fall out of the store loop (fp32 sums of the rounded fp16 values the consumer will read)
+      float cs[8], cq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
       for (int idx = tid; idx < BM * VPR; idx += 256) {
         const int r = idx / VPR, v = idx - r * VPR;
         const int m = m0 + r, n = n0 + v * 8;
-        if (m < p.M && n < p.N)
-          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
+        if (m < p.M && n < p.N) {
+          const half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = val;
+          if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = (float)val[j]; cs[j] += f; cq[j] += f * f; }
+          }
+        }
+      }
+      if (p.stats) {
+        // lanes sharing a vector index are VPR apart: fold them inside the wave, then across the 4 waves through LDS
+        float* sSt = reinterpret_cast<float*>(sOut + BM * OLD);       // [4][BN][2]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int off = VPR; off < 64; off <<= 1) { cs[j] += __shfl_xor(cs[j], off, 64); cq[j] += __shfl_xor(cq[j], off, 64); }
+        }
+        const int lane_ = tid & 63, wv = tid >> 6;
+        if (lane_ < VPR) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            sSt[(wv * BN + lane_ * 8 + j) * 2 + 0] = cs[j];
+            sSt[(wv * BN + lane_ * 8 + j) * 2 + 1] = cq[j];
+          }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) { s += sSt[(w4 * BN + tid) * 2]; q += sSt[(w4 * BN + tid) * 2 + 1]; }
+          float* dst = p.stats + ((size_t)blockIdx.x * p.N + n0 + tid) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
       }
     } else {
       // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
@@ -476,11 +513,48 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
     }
     __syncthreads();
     if (!p.geglu) {
+      // thread t owns the fixed 8-channel vector v = t % VPR and walks rows: per-channel sums for the GroupNorm that
+      // consumes this tensor fall out of the store loop (fp32 sums of the rounded fp16 values the consumer will read)
+      float cs[8], cq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
       for (int idx = tid; idx < BM * VPR; idx += 256) {
         const int r = idx / VPR, v = idx - r * VPR;
         const int m = m0 + r, n = n0 + v * 8;
-        if (m < p.M && n < p.N)
-          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
+        if (m < p.M && n < p.N) {
+          const half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = val;
+          if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = (float)val[j]; cs[j] += f; cq[j] += f * f; }
+          }
+        }
+      }
+      if (p.stats) {
+        // lanes sharing a vector index are VPR apart: fold them inside the wave, then across the 4 waves through LDS
+        float* sSt = reinterpret_cast<float*>(sOut + BM * OLD);       // [4][BN][2]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int off = VPR; off < 64; off <<= 1) { cs[j] += __shfl_xor(cs[j], off, 64); cq[j] += __shfl_xor(cq[j], off, 64); }
+        }
+        const int lane_ = tid & 63, wv = tid >> 6;
+        if (lane_ < VPR) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            sSt[(wv * BN + lane_ * 8 + j) * 2 + 0] = cs[j];
+            sSt[(wv * BN + lane_ * 8 + j) * 2 + 1] = cq[j];
+          }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) { s += sSt[(w4 * BN + tid) * 2]; q += sSt[(w4 * BN + tid) * 2 + 1]; }
+          float* dst = p.stats + ((size_t)blockIdx.x * p.N + n0 + tid) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
       }
     } else {
       // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
@@ -529,7 +603,7 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
 
 template <int BM, int BN, int BKT, int NST, int ABL = 0>
 static int launch_dma(const GemmP& p, dim3 grid, hipStream_t st, const half_t* zero_page) {
-  constexpr int ring = NST * (BM + BN) * BKT * 2, epi = BM * (BN + 8) * 2;   // the LDS epilogue re-uses the ring
+  constexpr int ring = NST * (BM + BN) * BKT * 2, epi = BM * (BN + 8) * 2 + 4 * BN * 2 * 4;   // the LDS epilogue re-uses the ring
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr = false;
   if (!attr) {
@@ -563,7 +637,7 @@ void gemm_defaults(GemmP& p) {
   p.B = 1; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.ksize = 1; p.stride = 1; p.pad = 0; p.ups = 0;
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
   p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1;
-  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0;
+  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr;
 }
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
@@ -588,7 +662,8 @@ int igemm_init() {
   return 0;
 }
 
-int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used) {
+int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used,
+                 int* stats_tile_rows) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -2;
   const int Cin = p.C1 + p.C2;
   if ((Cin & 7) || (p.K & 7) || (p.C1 & 7) || (p.ldw & 7) || (p.ldx1 & 7) || (p.C2 && (p.ldx2 & 7))) return -3;
@@ -638,6 +713,9 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.kchunks_per_split = (nchunks + split - 1) / split;
   p.epi_lds = (p.vt_col0 >= p.N) && (p.N % 8 == 0) && (p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
   if (p.geglu && !(p.epi_lds && fast && g_use_dma && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
+  const bool dma_ok = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
+  if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
+  if (stats_tile_rows) *stats_tile_rows = p.stats ? (cfg == 0 ? 128 : 64) : 0;
   p.slab = ws;
   const bool dma = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
   if (cfg == 0) {

@@ -136,6 +136,70 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict_
   }
 }
 
+// Small feature maps (16x16 / 8x8 levels): one block per (batch item, group) does everything in ONE launch -- the group's
+// HW x cpg slice is parked in LDS between the statistics pass and the apply pass.  These tensors are < 1 MB; three dependent
+// launches were pure latency.
+__global__ void __launch_bounds__(256) gn_small_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1, int C2,
+                                                       int HW, int G, float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int silu, half_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  half4* s_x = reinterpret_cast<half4*>(smem_raw);     // [HW * cpg / 4]
+  __shared__ float s_s[4], s_q[4];
+  const int C = C1 + C2, cpg = C / G, v4 = cpg >> 2;
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int nvec = HW * v4;
+  float s = 0.f, q = 0.f;
+  for (int idx = tid; idx < nvec; idx += 256) {
+    const int pix = idx / v4, v = idx - pix * v4;
+    const int c = g * cpg + 4 * v;
+    const half_t* src = c < C1 ? x1 + ((size_t)b * HW + pix) * C1 + c : x2 + ((size_t)b * HW + pix) * C2 + (c - C1);
+    const half4 val = *reinterpret_cast<const half4*>(src);
+    s_x[idx] = val;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float f = (float)val[j]; s += f; q += f * f; }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((tid & 63) == 0) { s_s[tid >> 6] = s; s_q[tid >> 6] = q; }
+  __syncthreads();
+  s = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+  q = (s_q[0] + s_q[1]) + (s_q[2] + s_q[3]);
+  const float n = (float)HW * (float)cpg;
+  const float mean = s / n;
+  float var = q / n - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  for (int idx = tid; idx < nvec; idx += 256) {
+    const int pix = idx / v4, v = idx - pix * v4;
+    const int c = g * cpg + 4 * v;
+    const half4 val = s_x[idx];
+    half4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sc = rstd * gamma[c + j];
+      float f = ((float)val[j] - mean) * sc + beta[c + j];
+      if (silu) f = silu_f(f);
+      o[j] = (half_t)f;
+    }
+    *reinterpret_cast<half4*>(out + ((size_t)b * HW + pix) * C + c) = o;
+  }
+}
+
+static bool gn_small_ok(int C1, int C2, int HW, int G) {
+  const int C = C1 + C2, cpg = C / G;
+  return (cpg % 4 == 0) && (C1 % 4 == 0) && ((size_t)HW * cpg <= 24576);
+}
+static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                           const float* beta, int silu, half_t* out, hipStream_t st) {
+  const int cpg = (C1 + C2) / G;
+  static bool attr = false;
+  if (!attr) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 2));
+    attr = true;
+  }
+  gn_small_kernel<<<dim3(B, G), 256, (size_t)HW * cpg * sizeof(half_t), st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
+  return (int)hipGetLastError();
+}
+
 static int gn_nchunk(int HW) { int n = HW / 64; if (n < 1) n = 1; if (n > 128) n = 128; return n; }
 static int gn_napply(int HW) { int n = HW / 16; if (n < 1) n = 1; if (n > 1024) n = 1024; return n; }
 
@@ -144,6 +208,7 @@ int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, 
                      const float* beta, int silu, half_t* out, float* partial, hipStream_t st) {
   const int C = C1 + C2;
   if ((C & 7) || (C1 & 7) || C % G || G > 64) return -3;
+  if (gn_small_ok(C1, C2, HW, G)) return launch_gn_small(x1, x2, C1, C2, B, HW, G, eps, gamma, beta, silu, out, st);
   const int C8 = C >> 3;
   const int TC = C8 < 256 ? C8 : 256, TP = 256 / TC;
   const int nchunk = gn_nchunk(HW);
@@ -151,6 +216,54 @@ int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, 
   size_t lds1 = (size_t)TP * C * 2 * sizeof(float);
   gn_stats_kernel<<<dim3(B, nchunk), 256, lds1, st>>>(x1, x2, C1, C2, HW, G, nchunk, partial);
   gn_finalize_kernel<<<B, 256, 0, st>>>(partial, C, HW, G, nchunk, eps, gamma, beta, ss);
+  const int napply = gn_napply(HW);
+  gn_apply_kernel<<<dim3(B, napply), 256, (size_t)2 * C * sizeof(float), st>>>(x1, x2, C1, C2, HW, napply, ss, silu, out);
+  return (int)hipGetLastError();
+}
+
+// Finalize from per-(m-tile, channel) partial sums written by the producer GEMM epilogues (two-source concat allowed).
+// One block per (batch item, group): cpg * tiles partial pairs are summed by 256 threads (fixed order: strided + tree).
+__global__ void __launch_bounds__(256) gn_finalize_tiles_kernel(const float* __restrict__ st1, int C1, int tpb1,
+                                                                const float* __restrict__ st2, int C2, int tpb2, int HW, int G,
+                                                                float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ ss) {
+  __shared__ float s_s[4], s_q[4];
+  const int C = C1 + C2, cpg = C / G;
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  float s = 0.f, q = 0.f;
+  for (int cl = 0; cl < cpg; ++cl) {
+    const int c = g * cpg + cl;
+    const float* st; int cs, cc, tpb;
+    if (c < C1) { st = st1; cs = C1; cc = c; tpb = tpb1; } else { st = st2; cs = C2; cc = c - C1; tpb = tpb2; }
+    const float* base = st + ((size_t)b * tpb * cs + cc) * 2;
+    for (int t = tid; t < tpb; t += 256) { s += base[(size_t)t * cs * 2]; q += base[(size_t)t * cs * 2 + 1]; }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((tid & 63) == 0) { s_s[tid >> 6] = s; s_q[tid >> 6] = q; }
+  __syncthreads();
+  s = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+  q = (s_q[0] + s_q[1]) + (s_q[2] + s_q[3]);
+  const float n = (float)HW * (float)cpg;
+  const float mean = s / n;
+  float var = q / n - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  for (int cl = tid; cl < cpg; cl += 256) {
+    const int c = g * cpg + cl;
+    const float sc = rstd * gamma[c];
+    ss[((size_t)b * C + c) * 2 + 0] = sc;
+    ss[((size_t)b * C + c) * 2 + 1] = beta[c] - mean * sc;
+  }
+}
+
+int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                           const float* beta, int silu, half_t* out, const float* st1, int tpb1, const float* st2, int tpb2,
+                           float* scratch, hipStream_t st) {
+  const int C = C1 + C2;
+  if ((C & 7) || (C1 & 7) || C % G || G > 64) return -3;
+  if (gn_small_ok(C1, C2, HW, G)) return launch_gn_small(x1, x2, C1, C2, B, HW, G, eps, gamma, beta, silu, out, st);
+  float* ss = scratch;   // [B][C][2]
+  gn_finalize_tiles_kernel<<<dim3(B, G), 256, 0, st>>>(st1, C1, tpb1, st2, C2, tpb2, HW, G, eps, gamma, beta, ss);
   const int napply = gn_napply(HW);
   gn_apply_kernel<<<dim3(B, napply), 256, (size_t)2 * C * sizeof(float), st>>>(x1, x2, C1, C2, HW, napply, ss, silu, out);
   return (int)hipGetLastError();

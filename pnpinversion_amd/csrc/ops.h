@@ -23,13 +23,15 @@ struct GemmP {
   half_t* out; int ldo;
   void* outT; int vt_col0, vt_ld, vt_f32, rows_per_batch;
   float* slab; int splitk, kchunks_per_split;
+  float* stats;   // optional: per (m-tile, channel) sum / sum-of-squares of the fp16 output, [gridDim.x][N][2] (GroupNorm fusion)
   int geglu;      // N columns are [x(32) | gate(32)] interleaved groups; output has N/2 columns: x * gelu(gate)
   int epi_lds;    // set by launch_igemm: coalesced LDS-staged epilogue is applicable
 };
 void gemm_defaults(GemmP& p);
 // ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.
+// stats_tile_rows (out): rows per m-tile of the p.stats partials actually produced, 0 if this launch produced none
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0,
-                 int* cfg_used = nullptr);
+                 int* cfg_used = nullptr, int* stats_tile_rows = nullptr);
 int igemm_init();  // sets dynamic-LDS attributes once
 void igemm_set_dma(int on);  // 1 (default): LDS-DMA kernel where applicable; 0: register-staged v1 kernel everywhere
 
@@ -39,6 +41,11 @@ void igemm_set_dma(int on);  // 1 (default): LDS-DMA kernel where applicable; 0:
 // GroupNorm over NHWC (two-source concat allowed). partial: [B][nchunk][G][2] fp32 scratch.
 int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps,
                      const float* gamma, const float* beta, int silu, half_t* out, float* partial, hipStream_t st);
+// GroupNorm whose statistics were produced by the GEMM epilogues of the tensor's producer(s): st1/st2 are [tiles][C][2]
+// per-channel partial sums with tpb1/tpb2 m-tiles per batch item.
+int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps,
+                           const float* gamma, const float* beta, int silu, half_t* out, const float* st1, int tpb1,
+                           const float* st2, int tpb2, float* scratch, hipStream_t st);
 int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamma, const float* beta, half_t* out,
                      hipStream_t st);
 int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st);       // x [M][2I] -> out [M][I]
