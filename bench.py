@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--schedule", choices=("lockstep", "reference"), default="lockstep",
+                    help="lockstep: offsets + reconstruction + edit passes share one 12-row UNet launch per timestep; "
+                         "reference: the reference's phase order, one 4-row launch per pass and step (same work, same results)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,12 +112,13 @@ def main():
     from pnpinversion_amd import weights
 
     cfg = SD1
-    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=4, max_vae_images=2)
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 if args.schedule == "lockstep" else 4, max_vae_images=2)
     if rank == 0:
         pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0))
     if world > 1:
         broadcast_weights(pipe.engine, src=0)       # the one collective: RCCL broadcast of the packed arena over xGMI
     editor = P2PEditor(["directinversion+p2p"], "cuda:%d" % local_rank, num_ddim_steps=args.ddim_steps, pipeline=pipe)
+    editor.lockstep = args.schedule == "lockstep"
     eng = pipe.engine
 
     def one_edit(i):
@@ -177,7 +181,7 @@ def main():
             "config": {"workload": "single 512x512 image per rank, SD-1.x (seeded synthetic weights), directinversion+p2p, "
                                    "faithful schedule: 650 UNet sample-forwards + 1 VAE encode + 5 VAE decodes per image, "
                                    "Refine+Reweight+LocalBlend controller",
-                       "ddim_steps": args.ddim_steps, "images_per_step_per_gpu": 1,
+                       "ddim_steps": args.ddim_steps, "images_per_step_per_gpu": 1, "schedule": args.schedule,
                        "unet_sample_forwards_per_image": ctr["unet_sample_forwards"] / max(1, args.steps),
                        "algorithmic_tflop_per_image": per_rank_flops / max(1, args.steps) / 1e12},
             "whole_path_tflops_per_gpu": per_rank_flops / dt / 1e12,

@@ -166,6 +166,15 @@ int pnpi_edit_loop(pnpi_ctx* ctx, const float* x_T /*[nimg][4][h][w]*/, int nimg
                    const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* timesteps_host, float guidance_scale,
                    float* latents_out);
 
+/* The denoising half of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) as ONE loop: offset_calculate
+ * (inversion.py:375-391) and npass direct_inversion_p2p_guidance_forward passes (p2p_guidance_forward.py:135-173; the
+ * reference runs an AttentionStore reconstruction pass and the edit pass) advance in lock step, one UNet launch of
+ * (1 + npass) * 4 * nimg rows per timestep.  ctrl_host: nullable or [npass][nimg] (kind 0 = no attention edit).
+ * noise_loss_out [nsteps][nimg][2][4][h][w]; latents_out [npass][nimg][2][4][h][w]. */
+int pnpi_direct_edit(pnpi_ctx* ctx, const float* ddim_latents /*[nsteps+1][nimg][...]*/, int nimg, const float* context4,
+                     int npass, const pnpi_ctrl_desc* ctrl_host, int offset_rows, int nsteps, const int* timesteps_host,
+                     float guidance_scale, float* noise_loss_out, float* latents_out);
+
 /* ---- kernel-level entry points (used by tests/ and bench.py to exercise single kernels) ------------------------- */
 int pnpi_op_conv(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16, int C1, int C2, int B, int H, int W,
                  int ksize, int stride, int pad, int upsample, int Ho, int Wo, const void* w_f16 /*[N][k*k*(C1+C2)]*/,

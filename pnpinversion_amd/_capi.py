@@ -76,6 +76,7 @@ SYMBOLS = {
     "pnpi_ddim_invert": (_i, [_vp, _vp, _i, _vp, _i, _ip, _vp]),
     "pnpi_offset_calculate": (_i, [_vp, _vp, _i, _vp, _i, _ip, _f, _vp]),
     "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _vp]),
+    "pnpi_direct_edit": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CtrlDesc), _i, _i, _ip, _f, _vp, _vp]),
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     "pnpi_op_gemm": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "pnpi_op_gemm_geglu": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i]),

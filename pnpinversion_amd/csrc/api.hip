@@ -1242,6 +1242,58 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   return 0;
 }
 
+/* offset_calculate + npass guidance-forward passes of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) advanced in
+ * lock step: every pass walks the same timesteps and pass p's step i needs only noise_loss[i], which the offset pass produces
+ * at the same step -- so one UNet launch per step serves all (1 + npass) * 4 * nimg rows. */
+int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, int npass, const pnpi_ctrl_desc* ctrl_host,
+                     int offset_rows, int nsteps, const int* ts, float gs, float* noise_loss_out, float* latents_out) {
+  if (!c || !lat_all || !context4 || !ts || !noise_loss_out || !latents_out || nsteps <= 0 || npass <= 0 || nimg <= 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
+  const size_t CE = (size_t)g.ctx_len * g.cross_dim;
+  const int ratio = g.n_train_timesteps / nsteps, NI = (1 + npass) * nimg, rows = 4 * NI;
+  if (rows > c->max_rows) return fail(c, PNPI_EINVAL, "(1 + npass) * nimg * 4 exceeds max_unet_rows");
+  std::vector<pnpi_ctrl_desc> cds(NI);
+  memset(cds.data(), 0, cds.size() * sizeof(pnpi_ctrl_desc));      // the offset pass (pseudo-images 0..nimg-1) runs no controller
+  if (ctrl_host) for (int i = 0; i < npass * nimg; ++i) cds[nimg + i] = ctrl_host[i];
+  CKP(setup_ctrl(c, cds.data(), NI, rows));
+  float* lat = misc_f(c, (size_t)NI * 2 * E);
+  float* in = misc_f(c, (size_t)rows * E);
+  float* eps = misc_f(c, (size_t)rows * E);
+  float* ctxrep = misc_f(c, (size_t)rows * CE);
+  std::vector<int> expand(NI * 2), inmap(rows), ctxmap(rows);
+  for (int q = 0; q < NI; ++q) {
+    const int img = q % nimg;
+    expand[2 * q] = img; expand[2 * q + 1] = img;
+    for (int k = 0; k < 4; ++k) { inmap[4 * q + k] = 2 * q + (k & 1); ctxmap[4 * q + k] = 4 * img + k; }
+  }
+  int *d_expand, *d_inmap, *d_ctxmap;
+  CKP(upload_ints(c, expand, &d_expand));
+  CKP(upload_ints(c, inmap, &d_inmap));
+  CKP(upload_ints(c, ctxmap, &d_ctxmap));
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  CK(launch_gather_rows_f32(lat_all + (size_t)nsteps * nimg * E, d_expand, NI * 2, E, lat, c->st));
+  CK(launch_gather_rows_f32(context4, d_ctxmap, rows, CE, ctxrep, c->st));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[i];
+    CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
+    int r = unet_fwd(c, in, rows, t, ctxrep, true, i, eps);
+    if (r) return r;
+    float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+    const float* target = lat_all + (size_t)(nsteps - i - 1) * nimg * E;
+    float* nl = noise_loss_out + (size_t)i * nimg * 2 * E;
+    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nullptr, 0, target, nl, lat, c->st));
+    for (int p = 1; p <= npass; ++p) {
+      float* lp = lat + (size_t)p * nimg * 2 * E;
+      CK(launch_cfg_ddim_prev(eps + (size_t)p * nimg * 4 * E, lp, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, nullptr, lp, c->st));
+    }
+    CKP(apply_local_blend(c, lat, i));
+  }
+  CKH(hipMemcpyAsync(latents_out, lat + (size_t)nimg * 2 * E, (size_t)npass * nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------- kernel-level ops
 int pnpi_op_conv(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int H, int W, int ksize, int stride, int pad,
                  int ups, int Ho, int Wo, const void* w, const float* bias, const void* res, int N, void* out, int force_cfg,

@@ -31,10 +31,15 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
-  const int head = blockIdx.y;
-  const int* rw = p.rows + blockIdx.z * 4;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of (row, head)
+  // groups so that one group's K / V^T stay in one L2 instead of being fetched by all eight.
+  const int nqt = (p.Nq + 127) >> 7, T = nqt * p.heads * p.nrows, per = (T + 7) >> 3;
+  const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tix >= T) return;
+  const int qt = tix % nqt, head = (tix / nqt) % p.heads;
+  const int* rw = p.rows + (tix / (nqt * p.heads)) * 4;
   const int orow = rw[0], qrow = rw[1], krow = rw[2], vrow = rw[3];
-  const int qtok = blockIdx.x * 128 + wave * 32 + ql;
+  const int qtok = qt * 128 + wave * 32 + ql;
   const bool qok = qtok < p.Nq;
 
   half8 qf[KS];
@@ -183,10 +188,15 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, ql = lane & 31;
-  const int head = blockIdx.y;
-  const int* rw = p.rows + blockIdx.z * 4;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of (row, head)
+  // groups so that one group's K / V^T stay in one L2 instead of being fetched by all eight.
+  const int nqt = (p.Nq + 127) >> 7, T = nqt * p.heads * p.nrows, per = (T + 7) >> 3;
+  const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tix >= T) return;
+  const int qt = tix % nqt, head = (tix / nqt) % p.heads;
+  const int* rw = p.rows + (tix / (nqt * p.heads)) * 4;
   const int orow = rw[0], qrow = rw[1], krow = rw[2], vrow = rw[3];
-  const int qtok = blockIdx.x * 128 + wave * 32 + ql;
+  const int qtok = qt * 128 + wave * 32 + ql;
   const bool qok = qtok < p.Nq;
 
   half8 qf[KS];
@@ -317,7 +327,8 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
 int launch_attn_flash(const AttnP& p, hipStream_t st) {
   if (p.nrows <= 0) return 0;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.q_off & 7) || (p.k_off & 7) || (p.dh & 3) || (p.ldo & 3)) return -3;
-  dim3 grid((p.Nq + 127) / 128, p.heads, p.nrows);
+  const int total = ((p.Nq + 127) / 128) * p.heads * p.nrows;
+  dim3 grid((unsigned)(((total + 7) / 8) * 8), 1, 1);
   static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
   if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma) {
     attn_flash_dma64_kernel<<<grid, 256, 0, st>>>(p);

@@ -329,7 +329,20 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with a private L2), so the
+  // launch is 1-D and XCD x takes the x-th contiguous eighth of the tile list.  The list is ordered so that the operand
+  // that is expensive to re-fetch crosses the fabric once: tile_order 0 = n fastest (an XCD owns a band of m-tiles: the
+  // activation is read once, the weight by every XCD), 1 = m fastest (an XCD owns a band of (n, k-split) weight slices:
+  // the weight is read once -- the low-resolution 1280-channel convolutions, where the weight is 10x the activation).
+  int bx, by, bz;
+  {
+    const int T = p.gx * p.gy * p.gz, per = (T + 7) >> 3;
+    const int tix = p.tile_order == 2 ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);   // 2: ablation
+    if (tix >= T) return;
+    if (p.tile_order == 0) { by = tix % p.gy; const int t = tix / p.gy; bx = t % p.gx; bz = t / p.gx; }
+    else { bx = tix % p.gx; const int t = tix / p.gx; by = t % p.gy; bz = t / p.gy; }
+  }
+  const int m0 = bx * BM, n0 = by * BN;
   const int Cin = p.C1 + p.C2;
   const int HoWo = p.Ho * p.Wo;
 
@@ -380,7 +393,7 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
   const int nchunks = p.K / BKT;
   int kc0 = 0, kc1 = nchunks;
   if (p.splitk > 1) {   // kchunks_per_split is given in 64-wide chunks
-    kc0 = blockIdx.z * p.kchunks_per_split * (64 / BKT);
+    kc0 = bz * p.kchunks_per_split * (64 / BKT);
     kc1 = min(nchunks, kc0 + p.kchunks_per_split * (64 / BKT));
   }
   // incremental (tap, channel) position of the next chunk to issue: wave-uniform scalars
@@ -551,7 +564,7 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
           float s = 0.f, q = 0.f;
 #pragma unroll
           for (int w4 = 0; w4 < 4; ++w4) { s += sSt[(w4 * BN + tid) * 2]; q += sSt[(w4 * BN + tid) * 2 + 1]; }
-          float* dst = p.stats + ((size_t)blockIdx.x * p.N + n0 + tid) * 2;
+          float* dst = p.stats + ((size_t)bx * p.N + n0 + tid) * 2;
           dst[0] = s;
           dst[1] = q;
         }
@@ -588,7 +601,7 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
         float v[4] = {acc[mi][ni][4 * g + 0], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
         if (p.splitk > 1) {
           if (m < p.M) {
-            float* dst = p.slab + ((size_t)blockIdx.z * p.M + m) * p.N + nb;
+            float* dst = p.slab + ((size_t)bz * p.M + m) * p.N + nb;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               if (nb + j < p.N) dst[j] = v[j];
@@ -601,8 +614,18 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
   }
 }
 
+static int g_tile_order = -1;   // PNPI_TILE_ORDER: force 0 / 1 (ablation)
 template <int BM, int BN, int BKT, int NST, int ABL = 0>
-static int launch_dma(const GemmP& p, dim3 grid, hipStream_t st, const half_t* zero_page) {
+static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t* zero_page) {
+  GemmP p = p_in;
+  p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
+  {
+    const double bytes_a = 2.0 * p.B * p.H * p.W * (p.C1 + p.C2), bytes_w = 2.0 * (double)p.N * p.K;
+    p.tile_order = (bytes_a + 8 * bytes_w <= 8 * bytes_a + bytes_w) ? 0 : 1;
+    if (g_tile_order >= 0) p.tile_order = g_tile_order;
+  }
+  const int total = (int)(grid.x * grid.y * grid.z);
+  grid = dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
   constexpr int ring = NST * (BM + BN) * BKT * 2, epi = BM * (BN + 8) * 2 + 4 * BN * 2 * 4;   // the LDS epilogue re-uses the ring
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr = false;
@@ -651,6 +674,7 @@ int igemm_init() {
   if (const char* e = getenv("PNPI_IGEMM_DMA")) g_use_dma = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V128")) g_var128 = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V64")) g_var64 = atoi(e);
+  if (const char* e = getenv("PNPI_TILE_ORDER")) g_tile_order = atoi(e);
   if (!g_zero_page) {
     HIP_CHECK_RET(hipMalloc((void**)&g_zero_page, 4096));
     HIP_CHECK_RET(hipMemset(g_zero_page, 0, 4096));

@@ -26,6 +26,7 @@ struct GemmP {
   float* stats;   // optional: per (m-tile, channel) sum / sum-of-squares of the fp16 output, [gridDim.x][N][2] (GroupNorm fusion)
   int geglu;      // N columns are [x(32) | gate(32)] interleaved groups; output has N/2 columns: x * gelu(gate)
   int epi_lds;    // set by launch_igemm: coalesced LDS-staged epilogue is applicable
+  int gx, gy, gz, tile_order;   // set by the launcher: logical tile grid and XCD-aware traversal order (see igemm_dma_kernel)
 };
 void gemm_defaults(GemmP& p);
 // ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.

@@ -268,6 +268,25 @@ class NativeEngine:
         self._keep = (lat, ctx, ts)
         return out
 
+    def direct_edit(self, ddim_latents, context4, ctrls_per_pass, timesteps, guidance_scale, offset_rows=1):
+        """offset_calculate + len(ctrls_per_pass) guidance-forward passes in lock step (pnpi_direct_edit).
+        ctrls_per_pass: list (passes) of None | list[ControllerTables | None] (images).  -> (noise_loss, latents[npass])"""
+        lat, ctx = self._f32(ddim_latents), self._f32(context4)
+        n = len(timesteps)
+        nimg = lat.shape[1]
+        npass = len(ctrls_per_pass)
+        flat = []
+        for cp in ctrls_per_pass:
+            flat += list(cp) if cp is not None else [None] * nimg
+        assert len(flat) == npass * nimg
+        arr = _desc_array(flat)
+        nl = torch.empty(n, nimg, 2, *lat.shape[2:], device=self.device)
+        out = torch.empty(npass, nimg, 2, *lat.shape[2:], device=self.device)
+        ts, tsp = self._ts(timesteps)
+        self._call("pnpi_direct_edit", _p(lat), nimg, _p(ctx), npass, arr, int(offset_rows), n, tsp, float(guidance_scale), _p(nl), _p(out))
+        self._keep = (lat, ctx, ts, arr, flat)
+        return nl, out
+
     def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1):
         xT, ctx = self._f32(x_T), self._f32(context4)
         nl = self._f32(noise_loss) if noise_loss is not None else None

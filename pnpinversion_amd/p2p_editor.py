@@ -11,8 +11,10 @@ from .p2p.attention_control import AttentionStore, make_controller
 from .p2p.inversion import DirectInversion
 from .p2p.p2p_guidance_forward import (direct_inversion_p2p_guidance_forward,
                                        direct_inversion_p2p_guidance_forward_add_target)
+from .p2p.attention_control import register_attention_control
 from .pipeline import NativePipeline
 from .utils.utils import latent2image, load_512, txt_draw
+import torch
 
 
 class P2PEditor:
@@ -30,6 +32,9 @@ class P2PEditor:
                 pipeline = NativePipeline.synthetic(cfg, seed=weight_seed, device=device)
         self.ldm_stable = pipeline
         self.scheduler = pipeline.scheduler
+        # lock-step schedule (pnpi_direct_edit): offsets + reconstruction pass + edit pass share one UNet launch per timestep.
+        # False runs the reference's phase order call by call (invert -> forward -> forward); same results within tolerance.
+        self.lockstep = True
         self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
 
     def __call__(self, edit_method, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None, quantile=0.7,
@@ -58,6 +63,9 @@ class P2PEditor:
             image_gt = np.array(Image.fromarray(image_gt).resize((side, side)))
         prompts = [prompt_src, prompt_tar]
         null_inversion = DirectInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
+        if self.lockstep and self.ldm_stable.engine.max_unet_rows >= 12:
+            return self._edit_lockstep(null_inversion, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
+                                       self_replace_steps, blend_word, eq_params, is_replace_controller, add_target, return_stages, side)
         _, _, x_stars, noise_loss_list = null_inversion.invert(image_gt=image_gt, prompt=prompts, guidance_scale=guidance_scale)
         x_t = x_stars[-1]
         controller = AttentionStore()
@@ -73,6 +81,36 @@ class P2PEditor:
         latents, _ = forward(model=self.ldm_stable, prompt=prompts, controller=controller, noise_loss_list=noise_loss_list,
                              latent=x_t, num_inference_steps=self.num_ddim_steps, guidance_scale=guidance_scale, generator=None)
         images = latent2image(model=self.ldm_stable.vae, latents=latents)
+        image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
+        panel = Image.fromarray(np.concatenate((image_instruct, image_gt, reconstruct_image, images[-1]), axis=1))
+        if return_stages:
+            return panel, dict(x_stars=x_stars, noise_loss_list=noise_loss_list, reconstruct_latent=reconstruct_latent,
+                               latents=latents, reconstruct_image=reconstruct_image, edited_image=images[-1])
+        return panel
+
+    @torch.no_grad()
+    def _edit_lockstep(self, inv, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps, self_replace_steps,
+                       blend_word, eq_params, is_replace_controller, add_target, return_stages, side):
+        """Same phases as models/p2p_editor.py:415-479, re-scheduled: after the 50 B=1 inversion steps, offset_calculate
+        (inversion.py:375-391), the AttentionStore reconstruction pass and the edit pass (p2p_guidance_forward.py:135-173) walk
+        the same 50 timesteps and only exchange noise_loss[i] at step i, so they run as ONE 12-row UNet launch per step."""
+        model = self.ldm_stable
+        model.scheduler.set_timesteps(self.num_ddim_steps)
+        inv.init_prompt(prompts)
+        register_attention_control(model, None)
+        _, x_stars = inv.ddim_inversion(image_gt)
+        controller = make_controller(pipeline=model, prompts=prompts, is_replace_controller=is_replace_controller,
+                                     cross_replace_steps={"default_": cross_replace_steps}, self_replace_steps=self_replace_steps,
+                                     blend_words=blend_word, equilizer_params=eq_params, num_ddim_steps=self.num_ddim_steps,
+                                     device=self.device)
+        register_attention_control(model, controller)
+        nl, lats = model.engine.direct_edit(torch.stack(x_stars), inv.context[None], [None, [controller.tables()]],
+                                            model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1)
+        controller.cur_step += self.num_ddim_steps
+        noise_loss_list = [nl[i, 0] for i in range(nl.shape[0])]
+        reconstruct_latent, latents = lats[0, 0], lats[1, 0]
+        reconstruct_image = latent2image(model=model.vae, latents=reconstruct_latent)[0]
+        images = latent2image(model=model.vae, latents=latents)
         image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
         panel = Image.fromarray(np.concatenate((image_instruct, image_gt, reconstruct_image, images[-1]), axis=1))
         if return_stages:

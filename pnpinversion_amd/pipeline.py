@@ -77,7 +77,7 @@ class NativeUNet:
 
 
 class NativePipeline:
-    def __init__(self, cfg: ModelConfig = SD1, device=None, max_unet_rows=4, max_vae_images=2, tokenizer=None, text_encoder=None,
+    def __init__(self, cfg: ModelConfig = SD1, device=None, max_unet_rows=12, max_vae_images=2, tokenizer=None, text_encoder=None,
                  scheduler=None):
         self.engine = NativeEngine(cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images)
         self.device = self.engine.device

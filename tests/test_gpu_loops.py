@@ -44,7 +44,7 @@ def masked_rel(a, b, tol_frac=0.005, pix_tol=0.25):
 @pytest.fixture(scope="module")
 def small64():
     cfg = SMALL64
-    pipe = NativePipeline(cfg, max_unet_rows=4, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
     pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
     yield pipe
     pipe.engine.close()
@@ -87,12 +87,51 @@ def test_loops_against_reference_golden(small64, name):
 
 
 @pytest.mark.parametrize("name", ["refine", "replace"])
-def test_p2p_editor_end_to_end_against_reference_golden(small64, name):
+def test_lockstep_loop_matches_phase_by_phase(small64, name):
+    """pnpi_direct_edit (offsets + reconstruction + edit pass in one 12-row launch per step) against the three separate loop
+    calls on the same inputs.  Rows are independent in every kernel and a launch uses one tile configuration for all of its
+    rows; only the per-launch tile / split-K choice differs with the row count, i.e. fp32 summation order."""
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % name))
+    pipe = small64
+    eng = pipe.engine
+    steps = int(g["steps"])
+    pipe.scheduler.set_timesteps(steps)
+    ts = pipe.scheduler.timesteps.numpy()
+    ctx = torch.from_numpy(g["context"]).float()
+    x_stars = torch.from_numpy(g["x_stars"])
+    w0, w1 = [str(x) for x in g["blend"]]
+    use_blend, is_replace = bool(g["use_blend"]), bool(g["is_replace"])
+    ctrl = ac.make_controller(pipe, [str(g["src"]), str(g["tgt"])], is_replace, {"default_": 0.4}, 0.6,
+                              ((w0,), (w1,)) if use_blend else None, {"words": (w1,), "values": (2,)} if use_blend else None,
+                              num_ddim_steps=steps)
+    nl_a = eng.offset_calculate(x_stars, ctx[None], ts, 7.5)
+    rec_a = eng.edit_loop(x_stars[-1], ctx[None], nl_a, None, ts, 7.5)[0]
+    out_a = eng.edit_loop(x_stars[-1], ctx[None], nl_a, [ctrl.tables()], ts, 7.5)[0]
+    nl_b, lats = eng.direct_edit(x_stars, ctx[None], [None, [ctrl.tables()]], ts, 7.5)
+    assert nl_b.shape == nl_a.shape and lats.shape[0] == 2
+    assert rel(nl_b, nl_a) < 1.5e-2, rel(nl_b, nl_a)      # offsets are small differences of latents: same bar as vs the reference
+    assert rel(lats[0, 0], rec_a) < 1e-2, rel(lats[0, 0], rec_a)
+    r, frac = masked_rel(lats[1, 0], out_a)
+    assert frac <= 0.005 and r < 1e-2, (r, frac)
+    # and directly against the reference's stage outputs, same bars as the phase-by-phase test
+    assert rel(nl_b[:, 0], g["noise_loss"]) < 1.5e-2
+    assert rel(lats[0, 0][1], g["reconstruct_latent"][1]) < 1.5e-2
+    r, frac = masked_rel(lats[1, 0][1], torch.from_numpy(g["edited_latents"])[1])
+    assert frac <= 0.005 and r < 1.5e-2, (r, frac)
+    assert rel(lats[1, 0][0], x_stars[0][0]) < 2e-2
+    # the source rows of the reconstruction and the edit pass are the same computation in the same launch: bit-identical
+    assert torch.equal(lats[0, 0][0], lats[1, 0][0])
+
+
+@pytest.mark.parametrize("lockstep", [True, False])
+@pytest.mark.parametrize("name", ["refine", "replace"])
+def test_p2p_editor_end_to_end_against_reference_golden(small64, name, lockstep):
     """Drop-in API: P2PEditor(...)(edit_method, image, prompts, ...) -> 4-panel PIL image; compared with the panels the
     reference's own P2PEditor produced from the same image / prompts / weights (stored 4x subsampled)."""
     g = np.load(os.path.join(GOLD, "e2e_%s.npz" % name))
     steps = int(g["steps"])
     ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=small64)
+    ed.lockstep = lockstep
     from PIL import Image
     img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
     w0, w1 = [str(x) for x in g["blend"]]

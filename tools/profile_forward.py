@@ -8,7 +8,8 @@ from pnpinversion_amd.engine import NativeEngine
 
 def main():
     cfg = SD1
-    eng = NativeEngine(cfg, max_unet_rows=4, max_vae_images=1)
+    ROWS = [int(x) for x in os.environ.get("ROWS", "1,4").split(",")]
+    eng = NativeEngine(cfg, max_unet_rows=max(ROWS), max_vae_images=1)
     # random weights directly on the GPU (values irrelevant for timing, but not all-zero: DVFS)
     g = torch.Generator(device="cuda").manual_seed(0)
     usd = {k: (torch.randn(v.shape, device="cuda", generator=g) * 0.02) for k, v in weights.unet_state_dict.__wrapped__(cfg).items()} if hasattr(weights.unet_state_dict, "__wrapped__") else None
@@ -20,7 +21,7 @@ def main():
         vsd = {k: v.cuda() for k, v in weights.vae_state_dict(cfg, 0).items()}
     eng.load_state_dict(usd, vsd)
     res = {}
-    for rows in (1, 4):
+    for rows in ROWS:
         lat = torch.randn(rows, 4, 64, 64, device="cuda")
         ctx = torch.randn(rows, 77, 768, device="cuda")
         for _ in range(3):
