@@ -316,7 +316,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // ABL: 0 = product kernel; 1 = DMA only (no fragment reads / MFMA); 2 = compute only (no DMA) -- bottleneck ablations for tools/.
 template <int BM, int BN, int BKT, int NST, int ABL = 0>
-__global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
+__global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   static_assert(BKT == 64 || BKT == 32, "BKT");
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int RPI = 1024 / (BKT * 2);                // tile rows per 1-KiB DMA instruction (8 or 16)
@@ -379,7 +379,15 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
     a_x0[i] = xo * p.stride - p.pad;
   }
   const int lim_y = p.ups ? 2 * p.H : p.H, lim_x = p.ups ? 2 * p.W : p.W, ups_sh = p.ups ? 1 : 0;
-  const half_t* w_ptr[WV];
+  const int nchunks = p.K / BKT;
+  int kc0 = 0, kc1 = nchunks;
+  if (p.splitk > 1) {   // kchunks_per_split is given in 64-wide chunks
+    kc0 = bz * p.kchunks_per_split * (64 / BKT);
+    kc1 = min(nchunks, kc0 + p.kchunks_per_split * (64 / BKT));
+  }
+  // Weight rows: one pointer per DMA instruction, bumped by BKT per chunk.  Rows past N read the zero page, which is as long
+  // as the longest K this kernel is launched with, so they are bumped like the others (no select in the loop).
+  const half_t* w_cur[WV];
 #pragma unroll
   for (int i = 0; i < WV; ++i) {
     const int j = wave * WV + i;
@@ -387,45 +395,52 @@ __global__ void __launch_bounds__(256) igemm_dma_kernel(GemmP p, const half_t* _
     if (BKT == 64) { const int line = 4 * (j & 1) + (lane >> 4); R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line; ch = (lane & 7) ^ line; }
     else { R = j * 16 + d_row; ch = d_chunk; }
     const int n = n0 + R;
-    w_ptr[i] = n < p.N ? p.w + (size_t)n * p.ldw + ch * 8 : zero_page;
+    w_cur[i] = (n < p.N ? p.w + (size_t)n * p.ldw : zero_page) + ch * 8 + kc0 * BKT;
   }
 
-  const int nchunks = p.K / BKT;
-  int kc0 = 0, kc1 = nchunks;
-  if (p.splitk > 1) {   // kchunks_per_split is given in 64-wide chunks
-    kc0 = bz * p.kchunks_per_split * (64 / BKT);
-    kc1 = min(nchunks, kc0 + p.kchunks_per_split * (64 / BKT));
-  }
-  // incremental (tap, channel) position of the next chunk to issue: wave-uniform scalars
-  int is_tap = (kc0 * BKT) / Cin;
+  // Activation rows: the (tap, source, bounds) part of the gather address changes only when the k-chunk walks into a new
+  // filter tap or from the first concat source into the second; inside a tap consecutive chunks are consecutive channels.
+  // So the full address (bounds test, 64-bit multiply, zero-page select) is rebuilt under a wave-uniform branch on those
+  // boundaries only, and the per-chunk work is one pointer bump per DMA instruction.
+  int is_tap = (kc0 * BKT) / Cin;              // wave-uniform scalars
   int is_c0 = kc0 * BKT - is_tap * Cin;
-  int is_kk = kc0 * BKT;
+  bool retap = true;
+  const half_t* a_cur[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) a_cur[i] = zero_page;
 
   auto issue = [&](int buf) {
     char* sA = smem_raw + buf * STAGE;
     char* sW = sA + BM * ROWB;
-    int r = 0, s = 0;
-    if (p.ksize == 3) { r = is_tap / 3; s = is_tap - 3 * r; }
-    const half_t* src; int ld, cc;
-    if (is_c0 < p.C1) { src = p.x1; ld = p.ldx1; cc = is_c0; } else { src = p.x2; ld = p.ldx2; cc = is_c0 - p.C1; }
-    const long zoff = zero_page - src;   // element distance to the zero page (plain integer arithmetic on addresses)
+    if (retap) {
+      int r = 0, s = 0;
+      if (p.ksize == 3) { r = is_tap / 3; s = is_tap - 3 * r; }
+      const half_t* src; int ld, cc;
+      if (is_c0 < p.C1) { src = p.x1; ld = p.ldx1; cc = is_c0; } else { src = p.x2; ld = p.ldx2; cc = is_c0 - p.C1; }
+      const long zoff = zero_page - src;   // element distance to the zero page (plain integer arithmetic on addresses)
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int yi = a_y0[i] + r, xi = a_x0[i] + s;
+        const bool ok = (unsigned)yi < (unsigned)lim_y && (unsigned)xi < (unsigned)lim_x;
+        const long off = (long)((a_bh[i] + (yi >> ups_sh)) * p.W + (xi >> ups_sh)) * ld + (cc + a_chunk[i]);
+        const long mask = -(long)ok;                       // all ones when in range: select without control flow
+        a_cur[i] = src + ((off & mask) | ((zoff + a_chunk[i]) & ~mask));
+      }
+      retap = false;
+    }
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-      const int yi = a_y0[i] + r, xi = a_x0[i] + s;
-      const bool ok = (unsigned)yi < (unsigned)lim_y && (unsigned)xi < (unsigned)lim_x;
-      const long off = (long)((a_bh[i] + (yi >> ups_sh)) * p.W + (xi >> ups_sh)) * ld + (cc + a_chunk[i]);
-      const long mask = -(long)ok;                       // all ones when in range: select without control flow
-      const half_t* g = src + ((off & mask) | (zoff & ~mask));
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sA + (wave * AV + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)a_cur[i], (lds_ptr_t)(sA + (wave * AV + i) * 1024), 16, 0, 0);
+      a_cur[i] += BKT;
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-      const half_t* g = w_ptr[i] + (w_ptr[i] == zero_page ? 0 : is_kk);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sW + (wave * WV + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)w_cur[i], (lds_ptr_t)(sW + (wave * WV + i) * 1024), 16, 0, 0);
+      w_cur[i] += BKT;
     }
-    is_kk += BKT;
     is_c0 += BKT;
-    if (is_c0 >= Cin) { is_c0 = 0; ++is_tap; }
+    if (is_c0 >= Cin) { is_c0 = 0; ++is_tap; retap = true; }
+    else if (is_c0 == p.C1) retap = true;
   };
 
   floatx16 acc[MI][NI];
@@ -666,18 +681,20 @@ void gemm_defaults(GemmP& p) {
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
 
 static half_t* g_zero_page = nullptr;
+static constexpr size_t ZERO_PAGE_BYTES = 128 << 10;   // >= 2 * (longest K + one chunk): out-of-range rows walk it like real rows
 static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
-static int g_var128 = 2, g_var64 = 0;   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
+static int g_var128 = 2, g_var64 = 0, g_var256 = 0;   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
 void igemm_set_dma(int on) { g_use_dma = on; }
 
 int igemm_init() {
   if (const char* e = getenv("PNPI_IGEMM_DMA")) g_use_dma = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V128")) g_var128 = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V64")) g_var64 = atoi(e);
+  if (const char* e = getenv("PNPI_IGEMM_V256")) g_var256 = atoi(e);
   if (const char* e = getenv("PNPI_TILE_ORDER")) g_tile_order = atoi(e);
   if (!g_zero_page) {
-    HIP_CHECK_RET(hipMalloc((void**)&g_zero_page, 4096));
-    HIP_CHECK_RET(hipMemset(g_zero_page, 0, 4096));
+    HIP_CHECK_RET(hipMalloc((void**)&g_zero_page, ZERO_PAGE_BYTES));
+    HIP_CHECK_RET(hipMemset(g_zero_page, 0, ZERO_PAGE_BYTES));
   }
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(128, 128)));
   HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(128, 128)));
@@ -732,17 +749,22 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (cfg == 0 && force_split > 1) {
     split = force_split;
   }
-  if (cfg_used) *cfg_used = split > 1 ? 2 : (cfg == 0 ? 0 : 1);
+  if (cfg_used) *cfg_used = split > 1 ? 2 : ((cfg == 0 || cfg == 3) ? 0 : 1);
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   p.epi_lds = (p.vt_col0 >= p.N) && (p.N % 8 == 0) && (p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
   if (p.geglu && !(p.epi_lds && fast && g_use_dma && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
-  const bool dma_ok = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
+  const bool dma_ok = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0) && ((size_t)p.K * 2 + 1024 <= ZERO_PAGE_BYTES);
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
-  if (stats_tile_rows) *stats_tile_rows = p.stats ? (cfg == 0 ? 128 : 64) : 0;
+  if (cfg == 3 && !(dma_ok && split == 1)) cfg = 0;               // the 256x128 tile exists only as an unsplit LDS-DMA kernel
+  if (stats_tile_rows) *stats_tile_rows = p.stats ? (cfg == 3 ? 256 : cfg == 0 ? 128 : 64) : 0;
   p.slab = ws;
-  const bool dma = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0);
-  if (cfg == 0) {
+  const bool dma = dma_ok;
+  if (cfg == 3) {
+    dim3 grid((p.M + 255) / 256, (p.N + 127) / 128, 1);
+    int r = g_var256 == 1 ? launch_dma<256, 128, 32, 2>(p, grid, st, g_zero_page) : launch_dma<256, 128, 32, 3>(p, grid, st, g_zero_page);
+    if (r) return r;
+  } else if (cfg == 0) {
     dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, split);
     if (dma) {
       int r;
@@ -753,6 +775,8 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
         case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
         case 11: r = launch_dma<128, 128, 32, 3, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
         case 12: r = launch_dma<128, 128, 32, 3, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
+        case 13: r = launch_dma<128, 128, 64, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only, 128-byte rows
+        case 14: r = launch_dma<128, 128, 64, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only, 128-byte rows
         default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;
       }
       if (r) return r;

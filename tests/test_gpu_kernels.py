@@ -32,6 +32,7 @@ def h16(*shape, scale=1.0, seed=0):
     (256, 256, 128, 0, 0), (256, 256, 128, 1, 0), (256, 256, 512, 2, 4),
     (130, 70, 72, -1, 0), (4096, 320, 320, -1, 0), (308, 640, 768, -1, 0), (64, 1280, 5120, -1, 0),
     (1, 8, 8, -1, 0), (33, 4, 2880, 1, 0), (100, 36, 1032, 2, 3),
+    (512, 256, 128, 3, 0), (700, 320, 640, 3, 0),        # 256x128 tile (ragged M and N)
 ])
 def test_gemm(ctx, M, N, K, cfg, split):
     a = h16(M, K, seed=1)
@@ -84,6 +85,8 @@ def pack_w(w):  # [N, C, kh, kw] -> [N, kh*kw*C] tap-major
     (2, 64, 0, 8, 64, 1, 1, 1, -1, 0),        # nearest-2x upsample folded into the conv
     (4, 1280, 0, 8, 128, 1, 1, 0, 2, 4),      # deep K, split-K
     (2, 128, 64, 8, 4, 1, 1, 0, -1, 0),       # tiny N (conv_out style), concat with generic... C1=128 fast
+    (3, 64, 64, 16, 192, 1, 1, 0, 3, 0),      # 256x128 tile, concat, ragged M (768 rows) and N
+    (2, 64, 0, 8, 64, 1, 1, 1, 3, 0),         # 256x128 tile with the folded upsample
 ])
 def test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
     W = H
