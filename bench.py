@@ -162,6 +162,8 @@ def main():
         ach = gemm[dom]["flops"] / (gemm[dom]["total_ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (%s)" % dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "alg_flop_per_launch": gemm[dom]["flops"] / max(1, gemm[dom]["launches"]),
+                    "alg_bytes_per_launch": gemm[dom]["bytes"] / max(1, gemm[dom]["launches"]),
                     "launches": gemm[dom]["launches"], "avg_launch_us": gemm[dom]["total_ms"] * 1e3 / max(1, gemm[dom]["launches"]),
                     "all_igemm_achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                     "classes": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
@@ -170,6 +172,16 @@ def main():
                                 for k, v in classes.items()}}
 
     if rank == 0:
+        # HBM-side traffic of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of
+        # this same command, reduced by tools/pmc_summary.py (gfx950 correction applied there) and committed under profiles/.
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+        if roofline is not None and os.path.exists(pmc):
+            tag = "igemm_dma_kernelILi128ELi128" if roofline["kernel"].endswith("(igemm128)") else "igemm_dma_kernelILi64ELi64"
+            for name, v in json.load(open(pmc))["kernels"].items():
+                if tag in name:
+                    roofline["traffic"] = v["traffic_bytes"]
+                    roofline["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, mean per launch)"
+                    break
         n_img = args.steps * world
         per_rank_flops = (ctr["unet_sample_forwards"] * UNET_GFLOP * 1e9 + ctr["vae_encodes"] * VAE_ENC_TFLOP * 1e12 +
                           ctr["vae_decodes"] * VAE_DEC_TFLOP * 1e12)

@@ -321,7 +321,10 @@ static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops, StatsReq* s
     ProfRec pr; prof_open(c, pr);
     int used = 0;
     r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, &used, &srows);
-    prof_close(c, pr, used, alg_flops, 0.0, p.M, p.N, p.K, p.ksize);
+    // algorithmic HBM bytes: the input tensor(s) once, the weight once, the output once (+ the residual it adds)
+    const double in_rows = (double)p.B * p.H * p.W;
+    const double alg_bytes = 2.0 * (in_rows * (p.C1 + p.C2) + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.res ? 2.0 : 1.0));
+    prof_close(c, pr, used, alg_flops, alg_bytes, p.M, p.N, p.K, p.ksize);
   } else {
     r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, nullptr, &srows);
   }

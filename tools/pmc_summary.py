@@ -1,0 +1,25 @@
+"""Reduce rocprofv3 --pmc counter_collection CSVs (one pass FETCH_SIZE, one pass WRITE_SIZE) to per-kernel HBM-side traffic per
+launch, applying the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports wide coalesced reads by 2x; checked here
+on gn_apply_kernel, which reads exactly what it writes).  usage: pmc_summary.py fetch.csv write.csv out.json"""
+import collections, csv, json, sys
+
+def agg(fn, cn):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(fn)):
+        if r["Counter_Name"] != cn:
+            continue
+        k = r["Kernel_Name"]
+        d[k][0] += 1
+        d[k][1] += float(r["Counter_Value"])
+    return d
+
+f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
+out = {"unit": "bytes per launch (mean)", "correction": "FETCH_SIZE KB x 2 (gfx950), WRITE_SIZE KB x 1", "kernels": {}}
+for k in sorted(f, key=lambda k: -f[k][1]):
+    n, s = f[k]
+    wn, ws = w.get(k, [0, 0.0])
+    out["kernels"][k] = {"launches": n, "fetch_bytes": 2 * 1024 * s / n, "write_bytes": 1024 * ws / max(wn, 1),
+                         "traffic_bytes": 2 * 1024 * s / n + 1024 * ws / max(wn, 1)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k, v in list(out["kernels"].items())[:10]:
+    print("%-70s n=%6d  fetch %8.2f MB  write %8.2f MB" % (k[:70], v["launches"], v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6))
