@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--batch-images", type=int, default=4,
+                    help="after the headline measurement (one image at a time), also time this many images per set of launches "
+                         "(configs[2] style sweep batching; reported under \"batched\", never as value); 0/1 = skip")
     ap.add_argument("--schedule", choices=("lockstep", "reference"), default="lockstep",
                     help="lockstep: offsets + reconstruction + edit passes share one 12-row UNet launch per timestep; "
                          "reference: the reference's phase order, one 4-row launch per pass and step (same work, same results)")
@@ -112,7 +115,7 @@ def main():
     from pnpinversion_amd import weights
 
     cfg = SD1
-    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 if args.schedule == "lockstep" else 4, max_vae_images=2)
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=max(12 * max(1, args.batch_images), 12) if args.schedule == "lockstep" else 4, max_vae_images=2)
     if rank == 0:
         pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0))
     if world > 1:
@@ -171,6 +174,28 @@ def main():
                                     "GBps": (v["bytes"] / (v["total_ms"] * 1e-3) / 1e9) if v["total_ms"] > 0 and v["bytes"] > 0 else None}
                                 for k, v in classes.items()}}
 
+    batched = None
+    if args.batch_images > 1 and args.schedule == "lockstep":
+        nb = args.batch_images
+        def batch_edit(i):
+            imgs = [synthetic_image(5000 + 1000 * rank + nb * i + j) for j in range(nb)]
+            return editor.edit_images_directinversion(imgs, [PROMPT_SRC] * nb, [PROMPT_TGT] * nb, guidance_scale=7.5,
+                                                      cross_replace_steps=0.4, self_replace_steps=0.6,
+                                                      blend_words=[(("cat",), ("dog",))] * nb,
+                                                      eq_params=[{"words": ("dog",), "values": (2,)}] * nb)
+        batch_edit(0)
+        barrier()
+        tb = time.perf_counter()
+        batch_edit(1)
+        barrier()
+        dtb = time.perf_counter() - tb
+        if dist is not None:
+            tt = torch.tensor([dtb], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+        batched = {"images_per_launch_set_per_gpu": nb, "value": nb * world / dtb, "unit": "images/s", "ms_per_batch": dtb * 1e3,
+                   "note": "same faithful schedule per image; %d-row inversion launches, %d-row lock-step launches" % (nb, 12 * nb)}
+
     if rank == 0:
         # HBM-side traffic of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of
         # this same command, reduced by tools/pmc_summary.py (gfx950 correction applied there) and committed under profiles/.
@@ -200,6 +225,8 @@ def main():
             "whole_path_mfma_frac": per_rank_flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
             "roofline": roofline,
         }
+        if batched is not None:
+            out["batched"] = batched
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

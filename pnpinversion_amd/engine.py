@@ -77,6 +77,7 @@ class NativeEngine:
             msg = self.lib.pnpi_last_error(self.h)
             raise _capi.PnpiError(st, msg.decode() if msg else "?")
         self.max_unet_rows = max_unet_rows
+        self.max_vae_images = max_vae_images
         self.lat_hw = cfg.sample_size
         self.ac = None
         self.final_alpha = None

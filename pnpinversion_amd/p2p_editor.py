@@ -13,7 +13,7 @@ from .p2p.p2p_guidance_forward import (direct_inversion_p2p_guidance_forward,
                                        direct_inversion_p2p_guidance_forward_add_target)
 from .p2p.attention_control import register_attention_control
 from .pipeline import NativePipeline
-from .utils.utils import latent2image, load_512, txt_draw
+from .utils.utils import image2latent, latent2image, load_512, txt_draw
 import torch
 
 
@@ -117,3 +117,58 @@ class P2PEditor:
             return panel, dict(x_stars=x_stars, noise_loss_list=noise_loss_list, reconstruct_latent=reconstruct_latent,
                                latents=latents, reconstruct_image=reconstruct_image, edited_image=images[-1])
         return panel
+
+    @torch.no_grad()
+    def edit_images_directinversion(self, image_paths, prompts_src, prompts_tar, guidance_scale=7.5, cross_replace_steps=0.4,
+                                    self_replace_steps=0.6, blend_words=None, eq_params=None, is_replace_controller=False,
+                                    add_target=False, return_stages=False):
+        """`edit_image_directinversion` for a batch of images in one set of launches (the PIE-Bench sweep of
+        run_editing_p2p.py:239-300 visits images one by one; one GPU has room for many): the n inversions run as n-row
+        launches, the three 4-row passes of every image as one 12n-row launch per timestep.  Images are independent rows in
+        every kernel; per-image results equal the single-image call within the fp16 tolerance (tests/test_gpu_loops.py).
+        blend_words / eq_params: None or one entry per image.  Returns the list of 4-panel images."""
+        model, eng = self.ldm_stable, self.ldm_stable.engine
+        n = len(image_paths)
+        if not (len(prompts_src) == len(prompts_tar) == n):
+            raise ValueError("image_paths, prompts_src and prompts_tar must have the same length")
+        if eng.max_unet_rows < 12 * n:
+            raise ValueError(f"batch of {n} images needs a pipeline built with max_unet_rows >= {12 * n}")
+        side = eng.cfg.sample_size * eng.cfg.vae_scale
+        images_gt = []
+        for pth in image_paths:
+            im = load_512(pth)
+            if side != 512:
+                im = np.array(Image.fromarray(im).resize((side, side)))
+            images_gt.append(im)
+        model.scheduler.set_timesteps(self.num_ddim_steps)
+        ts = model.scheduler.timesteps.numpy()
+        inv = DirectInversion(model=model, num_ddim_steps=self.num_ddim_steps)
+        contexts, controllers = [], []
+        register_attention_control(model, None)
+        for i in range(n):
+            prompts = [prompts_src[i], prompts_tar[i]]
+            inv.init_prompt(prompts)
+            contexts.append(inv.context)
+            controllers.append(make_controller(pipeline=model, prompts=prompts, is_replace_controller=is_replace_controller,
+                                               cross_replace_steps={"default_": cross_replace_steps},
+                                               self_replace_steps=self_replace_steps,
+                                               blend_words=blend_words[i] if blend_words is not None else None,
+                                               equilizer_params=eq_params[i] if eq_params is not None else None,
+                                               num_ddim_steps=self.num_ddim_steps, device=self.device))
+        ctx = torch.stack(contexts)                                        # [n, 4, 77, 768]
+        z0 = image2latent(model.vae, np.stack(images_gt))                  # [n, 4, h, w]
+        latent2image(model.vae, z0)                                        # the reference's discarded image_rec decode (inversion.py:357)
+        x_stars = eng.ddim_invert(z0, ctx[:, 2], ts)                       # [steps+1, n, 4, h, w]
+        nl, lats = eng.direct_edit(x_stars, ctx, [None, [c.tables() for c in controllers]], ts, guidance_scale,
+                                   offset_rows=2 if add_target else 1)
+        for c in controllers:
+            c.cur_step += self.num_ddim_steps
+        rec_images = latent2image(model.vae, lats[0].reshape(2 * n, *lats.shape[3:]))
+        images = latent2image(model.vae, lats[1].reshape(2 * n, *lats.shape[3:]))
+        panels = []
+        for i in range(n):
+            instruct = txt_draw(f"source prompt: {prompts_src[i]}\ntarget prompt: {prompts_tar[i]}", target_size=(side, side))
+            panels.append(Image.fromarray(np.concatenate((instruct, images_gt[i], rec_images[2 * i], images[2 * i + 1]), axis=1)))
+        if return_stages:
+            return panels, dict(x_stars=x_stars, noise_loss=nl, reconstruct_latents=lats[0], latents=lats[1])
+        return panels

@@ -36,10 +36,14 @@ class NativeVAE:
 
     # fused uint8 paths used by utils.latent2image / image2latent
     def latent2image_u8(self, latents):
-        return self.engine.latent2image(latents.detach()).cpu().numpy()
+        latents, m = latents.detach(), self.engine.max_vae_images       # the VAE workspace holds max_vae_images images
+        return np.concatenate([self.engine.latent2image(latents[i:i + m]).cpu().numpy() for i in range(0, latents.shape[0], m)])
 
     def image2latent_u8(self, image):
-        return self.engine.image2latent(np.ascontiguousarray(image))
+        image, m = np.ascontiguousarray(image), self.engine.max_vae_images
+        if image.ndim == 3:
+            return self.engine.image2latent(image)
+        return torch.cat([self.engine.image2latent(image[i:i + m]) for i in range(0, image.shape[0], m)])
 
 
 class NativeUNet:

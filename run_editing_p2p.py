@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--output_path", type=str, default="output")
     ap.add_argument("--edit_category_list", nargs="+", type=str, default=[str(i) for i in range(10)])
     ap.add_argument("--edit_method_list", nargs="+", type=str, default=["directinversion+p2p"])
+    ap.add_argument("--batch_size", type=int, default=1, help="images per set of launches and GPU (not in the reference: it edits one by one)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,7 +56,7 @@ def main():
     from pnpinversion_amd import weights
     from pnpinversion_amd.config import SD1
     from pnpinversion_amd.pipeline import NativePipeline
-    pipe = NativePipeline(SD1, device="cuda:%d" % local_rank)
+    pipe = NativePipeline(SD1, device="cuda:%d" % local_rank, max_unet_rows=12 * max(1, args.batch_size))
     if rank == 0:
         pipe.load_state_dict(weights.unet_state_dict(SD1, 0), weights.vae_state_dict(SD1, 0))   # no SD checkpoint offline
     if world > 1:
@@ -65,27 +66,47 @@ def main():
     with open(os.path.join(args.data_path, "mapping_file.json")) as f:
         instructions = json.load(f)
     work = [(k, v) for k, v in instructions.items() if v["editing_type_id"] in args.edit_category_list]
-    for key, item in shard_items(work, rank, world):
+    def fields(item):
         src = item["original_prompt"].replace("[", "").replace("]", "")
         tgt = item["editing_prompt"].replace("[", "").replace("]", "")
         image_path = os.path.join(args.data_path, "annotation_images", item["image_path"])
         blended = item["blended_word"].split(" ") if item["blended_word"] != "" else []
-        _ = Image.fromarray(np.uint8(mask_decode(item["mask"])[:, :, None].repeat(3, 2))).convert("L")   # unused, as in the reference
-        for method in args.edit_method_list:
+        return src, tgt, image_path, blended
+
+    mine = list(shard_items(work, rank, world))
+    for method in args.edit_method_list:
+        todo = []
+        for key, item in mine:
+            src, tgt, image_path, blended = fields(item)
+            _ = Image.fromarray(np.uint8(mask_decode(item["mask"])[:, :, None].repeat(3, 2))).convert("L")   # unused, as in the reference
             out_path = image_path.replace(args.data_path, os.path.join(args.output_path, method))
             if os.path.exists(out_path) and not args.rerun_exist_images:
                 print(f"skip image [{image_path}] with [{method}]")
                 continue
-            print(f"editing image [{image_path}] with [{method}]")
+            todo.append((src, tgt, image_path, blended, out_path))
+        nb = args.batch_size if method == "directinversion+p2p" else 1
+        for b0 in range(0, len(todo), nb):
+            chunk = todo[b0:b0 + nb]
+            for (_, _, image_path, _, _) in chunk:
+                print(f"editing image [{image_path}] with [{method}]")
             setup_seed()
-            edited = editor(method, image_path=image_path, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5,
-                            cross_replace_steps=0.4, self_replace_steps=0.6,
-                            blend_word=((blended[0],), (blended[1],)) if blended else None,
-                            eq_params={"words": (blended[1],), "values": (2,)} if blended else None,
-                            proximal="l0", quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400)
-            os.makedirs(os.path.dirname(out_path), exist_ok=True)
-            edited.save(out_path)
-            print("finish")
+            if len(chunk) == 1:
+                src, tgt, image_path, blended, _ = chunk[0]
+                panels = [editor(method, image_path=image_path, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5,
+                                 cross_replace_steps=0.4, self_replace_steps=0.6,
+                                 blend_word=((blended[0],), (blended[1],)) if blended else None,
+                                 eq_params={"words": (blended[1],), "values": (2,)} if blended else None,
+                                 proximal="l0", quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400)]
+            else:   # several images per set of launches (12 UNet rows each); same per-image schedule and results
+                panels = editor.edit_images_directinversion(
+                    [c[2] for c in chunk], [c[0] for c in chunk], [c[1] for c in chunk], guidance_scale=7.5,
+                    cross_replace_steps=0.4, self_replace_steps=0.6,
+                    blend_words=[((c[3][0],), (c[3][1],)) if c[3] else None for c in chunk],
+                    eq_params=[{"words": (c[3][1],), "values": (2,)} if c[3] else None for c in chunk])
+            for panel, c in zip(panels, chunk):
+                os.makedirs(os.path.dirname(c[4]), exist_ok=True)
+                panel.save(c[4])
+                print("finish")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -189,3 +189,35 @@ def test_loops_against_oracle_tiny():
     assert rel(got_out[1], ref_out[1]) < 2e-2, rel(got_out[1], ref_out[1])
     assert rel(got_out[0], z0[0]) < 2e-2, rel(got_out[0], z0[0])
     eng.close()
+
+
+def test_batched_images_match_single_image_calls():
+    """P2PEditor.edit_images_directinversion: two images (different prompts, one with LocalBlend + reweight, one plain refine)
+    through one set of launches (2-row inversion, 24-row lock-step loop) against the two single-image calls."""
+    cfg = SMALL64
+    pipe = NativePipeline(cfg, max_unet_rows=24, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    steps = 3
+    ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=pipe)
+    from PIL import Image
+    img0 = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    img1 = np.ascontiguousarray(img0[:, ::-1])
+    src = ["a cat sitting on a wooden chair", "a photograph of a mountain"]
+    tgt = ["a dog sitting on a wooden chair", "a watercolor photograph of a snowy mountain"]
+    blend = [(("cat",), ("dog",)), None]
+    eq = [{"words": ("dog",), "values": (2,)}, None]
+    panels, st = ed.edit_images_directinversion([img0, img1], src, tgt, blend_words=blend, eq_params=eq, return_stages=True)
+    assert len(panels) == 2 and panels[0].size == (2048, 512)
+    for i, img in enumerate((img0, img1)):
+        p1, s1 = ed.edit_image_directinversion(img, src[i], tgt[i], blend_word=blend[i], eq_params=eq[i], return_stages=True)
+        xs = torch.stack([x for x in s1["x_stars"]])[:, 0]
+        assert rel(st["x_stars"][:, i], xs) < 5e-3, rel(st["x_stars"][:, i], xs)
+        assert rel(st["reconstruct_latents"][i], s1["reconstruct_latent"]) < 1.5e-2
+        r, frac = masked_rel(st["latents"][i], s1["latents"], tol_frac=0.01)
+        assert frac <= 0.01 and r < 1.5e-2, (i, r, frac)
+        a, b = np.array(panels[i]).astype(np.int32), np.array(p1).astype(np.int32)
+        assert np.abs(a[:, :1024] - b[:, :1024]).max() == 0            # instruction + ground-truth panels
+        assert np.abs(a[:, 1024:] - b[:, 1024:]).mean() < 2.0
+    with pytest.raises(ValueError, match="max_unet_rows"):
+        ed.edit_images_directinversion([img0] * 3, src + src[:1], tgt + tgt[:1])
+    pipe.engine.close()
