@@ -145,11 +145,12 @@ int pnpi_ddim_next_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, 
 /* DirectInversion.prev_step (inversion.py:247-260) == DDIMSchedulerDev.step (scheduler_dev.py:38-95), eta = 0 */
 int pnpi_ddim_prev_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, const float* sample, size_t n, float* out);
 /* fused CFG + prev_step + direct-inversion offset (inversion.py:383-389; p2p_guidance_forward.py:110-114).
- *   eps [nimg][2R][E]; x [nimg][R][E]; target (nullable) [nimg][E] -> offset_out = target - prev, x_out = prev + offset;
+ *   eps [nimg][2R][E]; x [nimg][R][E]; target (nullable) [nimg][E] -> offset_out = (target - prev) * offset_scale (1 on
+ *   the paper's path; the not_full / skip_step ablations scale or zero it, inversion.py:491-492,512-515), x_out = prev + offset;
  *   else noise_loss (nullable) [nimg][R][E] added to the first offset_rows rows. */
 int pnpi_cfg_ddim_prev(pnpi_ctx* ctx, const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems,
                        float guidance_scale, int t, int step_ratio, const float* noise_loss, int offset_rows,
-                       const float* target, float* offset_out, float* x_out);
+                       const float* target, float offset_scale, float* offset_out, float* x_out);
 
 /* ---- level 2: loop boundary (whole phases device-resident, no host round trip per step) ------------------------- */
 /* DirectInversion.ddim_loop (inversion.py:308-319): latents_out [nsteps+1][nimg][4][h][w]; timesteps_host = scheduler.timesteps */
@@ -158,7 +159,13 @@ int pnpi_ddim_invert(pnpi_ctx* ctx, const float* z0, int nimg, const float* ctx_
 /* DirectInversion.offset_calculate (inversion.py:375-391): noise_loss_out [nsteps][nimg][2][4][h][w] */
 int pnpi_offset_calculate(pnpi_ctx* ctx, const float* ddim_latents /*[nsteps+1][nimg][...]*/, int nimg,
                           const float* context4 /*[nimg][4][77][768]*/, int nsteps, const int* timesteps_host,
-                          float guidance_scale, float* noise_loss_out);
+                          float guidance_scale, const float* offset_scale_host /*[nsteps], nullable = all 1*/,
+                          float* noise_loss_out);
+/* DirectInversion.ddim_with_guidance_scale_loop (inversion.py:334-347): DDIM inversion under classifier-free guidance
+ * (the directinversion+p2p_guidance_<inv>_<fwd> methods); uncond / cond rows share one launch per step */
+int pnpi_ddim_invert_cfg(pnpi_ctx* ctx, const float* z0, int nimg, const float* ctx_uncond /*[nimg][77][768]*/,
+                         const float* ctx_cond, float guidance_scale, int nsteps, const int* timesteps_host,
+                         float* latents_out);
 /* direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) incl. controller + LocalBlend:
  * latents_out [nimg][2][4][h][w].  ctrl_host: nullable or [nimg]. */
 int pnpi_edit_loop(pnpi_ctx* ctx, const float* x_T /*[nimg][4][h][w]*/, int nimg, const float* context4,
@@ -173,7 +180,8 @@ int pnpi_edit_loop(pnpi_ctx* ctx, const float* x_T /*[nimg][4][h][w]*/, int nimg
  * noise_loss_out [nsteps][nimg][2][4][h][w]; latents_out [npass][nimg][2][4][h][w]. */
 int pnpi_direct_edit(pnpi_ctx* ctx, const float* ddim_latents /*[nsteps+1][nimg][...]*/, int nimg, const float* context4,
                      int npass, const pnpi_ctrl_desc* ctrl_host, int offset_rows, int nsteps, const int* timesteps_host,
-                     float guidance_scale, float* noise_loss_out, float* latents_out);
+                     float guidance_scale, const float* offset_scale_host /*[nsteps], nullable*/, float* noise_loss_out,
+                     float* latents_out);
 
 /* ---- kernel-level entry points (used by tests/ and bench.py to exercise single kernels) ------------------------- */
 int pnpi_op_conv(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16, int C1, int C2, int B, int H, int W,

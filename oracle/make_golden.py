@@ -10,6 +10,9 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_refine.npz       models/p2p_editor.py P2PEditor("directinversion+p2p") stage outputs, SMALL64, 2+2 steps,
                        AttentionRefine + AttentionReweight + LocalBlend (the PIE-Bench default controller)
   e2e_replace.npz      same with is_replace_controller=True (AttentionReplace), no blend / reweight
+  e2e_variants.npz     the reference's P2PEditor run on six more method strings that share the loop (ddim+p2p,
+                       negative-prompt-inversion+p2p, a vary-guidance, a not_full, a skip_step and the add-target ablation):
+                       inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
 """
 import json
 import os
@@ -152,10 +155,77 @@ def e2e(name, is_replace, blend, steps=2):
     print("e2e", name, "%.1fs" % (time.time() - t0))
 
 
+VARIANT_METHODS = ["ddim+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5",
+                   "ablation_directinversion_04+p2p", "ablation_directinversion_interval_2+p2p",
+                   "ablation_directinversion_add-target+p2p"]
+
+
+def variants(steps=2):
+    """Same image / prompts / weights / controller settings as e2e_refine, other method strings of P2PEditor.__call__."""
+    ref_shim.install()
+    cfg = SMALL64
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, w0, w1 = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    import models.p2p_editor as pe
+    import models.p2p.inversion as inv
+    out = {"methods": np.array(VARIANT_METHODS), "steps": np.int64(steps), "src": src, "tgt": tgt, "blend": np.array([w0, w1])}
+    fwd_names = ["direct_inversion_p2p_guidance_forward", "direct_inversion_p2p_guidance_forward_add_target", "p2p_guidance_forward",
+                 "proximal_guidance_forward"]
+    inv_names = ["invert", "invert_with_guidance_scale_vary_guidance", "invert_not_full", "invert_skip_step"]
+    for m in VARIANT_METHODS:
+        t0 = time.time()
+        calls, stages = [], {}
+        saved = {n: getattr(pe, n) for n in fwd_names}
+        saved_inv = {n: getattr(inv.DirectInversion, n) for n in inv_names}
+
+        def spy_fwd(f):
+            def g(*a, **k):
+                r = f(*a, **k)
+                calls.append(r[0].clone().numpy())
+                return r
+            return g
+
+        def spy_inv(f):
+            def g(self, *a, **k):
+                r = f(self, *a, **k)
+                stages["x_stars"] = torch.stack([x.clone() for x in r[2]]).numpy()
+                stages["noise_loss"] = torch.stack([x.clone() for x in r[3]]).numpy()
+                return r
+            return g
+
+        for n in fwd_names:
+            setattr(pe, n, spy_fwd(saved[n]))
+        for n in inv_names:
+            setattr(inv.DirectInversion, n, spy_inv(saved_inv[n]))
+        try:
+            with ref_shim.cuda_to_cpu(), torch.no_grad():
+                panel = ed(m, image_path=img, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5, cross_replace_steps=0.4,
+                           self_replace_steps=0.6, blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)},
+                           is_replace_controller=False)
+        finally:
+            for n in fwd_names:
+                setattr(pe, n, saved[n])
+            for n in inv_names:
+                setattr(inv.DirectInversion, n, saved_inv[n])
+        assert len(calls) == 2, (m, len(calls))
+        out[m + "/reconstruct_latent"] = calls[0]
+        out[m + "/edited_latents"] = calls[1]
+        if m.startswith("directinversion+p2p_guidance"):
+            out[m + "/x_stars"] = stages["x_stars"]
+        if "noise_loss" in stages and m != "ablation_directinversion_add-target+p2p":
+            out[m + "/noise_loss"] = stages["noise_loss"]
+        out[m + "/edited_image_small"] = np.array(panel)[::4, 3 * 512::4]
+        print("variant", m, "%.1fs" % (time.time() - t0), {k: v.shape for k, v in out.items() if k.startswith(m + "/")})
+    np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["host", "models", "e2e"]
+    which = sys.argv[1:] or ["host", "models", "e2e", "variants"]
     if "host" in which:
         host_tables()
     if "models" in which:
@@ -163,3 +233,5 @@ if __name__ == "__main__":
     if "e2e" in which:
         e2e("refine", False, True)
         e2e("replace", True, False)
+    if "variants" in which:
+        variants()

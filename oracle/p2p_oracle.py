@@ -177,8 +177,27 @@ def ddim_loop(unet_fn, z0, ctx_cond, timesteps, ac, final):
     return all_lat
 
 
-def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guidance_scale):
-    """DirectInversion.offset_calculate (inversion.py:375-391).  context4 rows = [unc_src, unc_tgt, cond_src, cond_tgt]."""
+def ddim_loop_cfg(unet_fn, z0, ctx_uncond, ctx_cond, timesteps, ac, final, guidance_scale):
+    """DirectInversion.ddim_with_guidance_scale_loop (inversion.py:334-347): two B = 1 UNet calls per step, CFG, next_step."""
+    n = len(timesteps)
+    ratio = len(ac) // n
+    lat = z0.clone()
+    all_lat = [z0]
+    for i in range(n):
+        t = int(timesteps[n - i - 1])
+        eu = unet_fn(lat, t, ctx_uncond, None)
+        ec = unet_fn(lat, t, ctx_cond, None)
+        e = eu + guidance_scale * (ec - eu)
+        a_from, a_to = next_alphas(ac, final, t, ratio)
+        lat = ddim_move(lat, e, float(a_from), float(a_to))
+        all_lat.append(lat)
+    return all_lat
+
+
+def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guidance_scale, offset_scale=None):
+    """DirectInversion.offset_calculate (inversion.py:375-391).  context4 rows = [unc_src, unc_tgt, cond_src, cond_tgt].
+    offset_scale: None | float (offset_calculate_not_full, :478-493: loss *= scale) | per-step list (offset_calculate_skip_step,
+    :502-519: loss = 0 on the steps with i % skip_step != 0)."""
     n = len(timesteps)
     ratio = len(ac) // n
     nrow = context4.shape[0] // 2
@@ -193,6 +212,9 @@ def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guid
         a_t, a_p = prev_alphas(ac, final, t, ratio)
         prev_rec = ddim_move(cur, e, float(a_t), float(a_p))
         loss = prev_target - prev_rec
+        if offset_scale is not None:
+            sc = offset_scale[i] if hasattr(offset_scale, "__len__") else offset_scale
+            loss = loss * sc if sc != 0 else torch.zeros_like(loss)
         losses.append(loss)
         cur = prev_rec + loss
     return losses

@@ -1148,9 +1148,10 @@ int pnpi_ddim_prev_step(pnpi_ctx* c, const float* eps, int t, int ratio, const f
   return 0;
 }
 int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, int rpi, size_t row_elems, float gs, int t, int ratio,
-                       const float* noise_loss, int offset_rows, const float* target, float* offset_out, float* x_out) {
+                       const float* noise_loss, int offset_rows, const float* target, float offset_scale, float* offset_out,
+                       float* x_out) {
   float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
-  CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_out, x_out, c->st));
+  CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_scale, offset_out, x_out, c->st));
   return 0;
 }
 
@@ -1175,13 +1176,52 @@ int pnpi_ddim_invert(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_co
   return 0;
 }
 
+static int upload_ints(pnpi_ctx* c, const std::vector<int>& v, int** dst);
+
+/* DirectInversion.ddim_with_guidance_scale_loop (inversion.py:334-347): inversion under classifier-free guidance.  The reference
+ * makes two B=1 UNet calls per step (uncond, cond); here they are the two rows of one launch. */
+int pnpi_ddim_invert_cfg(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_uncond, const float* ctx_cond, float gs, int nsteps,
+                         const int* ts, float* all) {
+  if (!c || !z0 || !ctx_uncond || !ctx_cond || !ts || !all || nsteps <= 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  const int ratio = g.n_train_timesteps / nsteps, rows = 2 * nimg;
+  if (rows > c->max_rows) return fail(c, PNPI_EINVAL, "nimg * 2 exceeds max_unet_rows");
+  CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  float* eps = misc_f(c, (size_t)rows * E);
+  float* in = misc_f(c, (size_t)rows * E);
+  float* ctx2 = misc_f(c, (size_t)rows * CE);
+  std::vector<int> inmap(rows);
+  for (int i = 0; i < nimg; ++i) { inmap[2 * i] = i; inmap[2 * i + 1] = i; }
+  int* d_inmap;
+  CKP(upload_ints(c, inmap, &d_inmap));
+  for (int i = 0; i < nimg; ++i) {   // rows [img][uncond, cond]
+    CKH(hipMemcpyAsync(ctx2 + (size_t)(2 * i) * CE, ctx_uncond + (size_t)i * CE, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+    CKH(hipMemcpyAsync(ctx2 + (size_t)(2 * i + 1) * CE, ctx_cond + (size_t)i * CE, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  }
+  CKH(hipMemcpyAsync(all, z0, (size_t)nimg * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[nsteps - i - 1];
+    const float* cur = all + (size_t)i * nimg * E;
+    CK(launch_gather_rows_f32(cur, d_inmap, rows, E, in, c->st));
+    int r = unet_fwd(c, in, rows, t, ctx2, false, 0, eps);
+    if (r) return r;
+    float af, at; CKP(alphas_for(c, t, ratio, true, &af, &at));
+    // noise = eps_u + gs * (eps_c - eps_u); next_step (the same fused kernel as the denoising direction, other alphas)
+    CK(launch_cfg_ddim_prev(eps, cur, nimg, 1, E, gs, af, at, nullptr, 0, nullptr, 1.f, nullptr, all + (size_t)(i + 1) * nimg * E, c->st));
+  }
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  return 0;
+}
+
 static int upload_ints(pnpi_ctx* c, const std::vector<int>& v, int** dst) {
   *dst = (int*)c->ctrl_arena.alloc(v.size() * sizeof(int));
   return upload(c, *dst, v.data(), v.size() * sizeof(int));
 }
 
 int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, int nsteps, const int* ts, float gs,
-                          float* noise_loss_out) {
+                          const float* offset_scale_host, float* noise_loss_out) {
   if (!c || !lat_all || !context4 || !ts || !noise_loss_out || nsteps <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   const pnpi_model_config& g = c->cfg;
@@ -1205,7 +1245,8 @@ int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const flo
     if (r) return r;
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* target = lat_all + (size_t)(nsteps - i - 1) * nimg * E;
-    CK(launch_cfg_ddim_prev(eps, cur, nimg, 2, E, gs, af, at, nullptr, 0, target, noise_loss_out + (size_t)i * nimg * 2 * E, cur, c->st));
+    CK(launch_cfg_ddim_prev(eps, cur, nimg, 2, E, gs, af, at, nullptr, 0, target, offset_scale_host ? offset_scale_host[i] : 1.f,
+                            noise_loss_out + (size_t)i * nimg * 2 * E, cur, c->st));
   }
   return 0;
 }
@@ -1237,7 +1278,7 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
     if (r) return r;
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
-    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, nullptr, lat, c->st));
+    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st));
     if (use_ctrl) CKP(apply_local_blend(c, lat, i));
   }
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
@@ -1249,7 +1290,8 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
  * lock step: every pass walks the same timesteps and pass p's step i needs only noise_loss[i], which the offset pass produces
  * at the same step -- so one UNet launch per step serves all (1 + npass) * 4 * nimg rows. */
 int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, int npass, const pnpi_ctrl_desc* ctrl_host,
-                     int offset_rows, int nsteps, const int* ts, float gs, float* noise_loss_out, float* latents_out) {
+                     int offset_rows, int nsteps, const int* ts, float gs, const float* offset_scale_host, float* noise_loss_out,
+                     float* latents_out) {
   if (!c || !lat_all || !context4 || !ts || !noise_loss_out || !latents_out || nsteps <= 0 || npass <= 0 || nimg <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   const pnpi_model_config& g = c->cfg;
@@ -1286,10 +1328,10 @@ int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* c
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* target = lat_all + (size_t)(nsteps - i - 1) * nimg * E;
     float* nl = noise_loss_out + (size_t)i * nimg * 2 * E;
-    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nullptr, 0, target, nl, lat, c->st));
+    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nullptr, 0, target, offset_scale_host ? offset_scale_host[i] : 1.f, nl, lat, c->st));
     for (int p = 1; p <= npass; ++p) {
       float* lp = lat + (size_t)p * nimg * 2 * E;
-      CK(launch_cfg_ddim_prev(eps + (size_t)p * nimg * 4 * E, lp, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, nullptr, lp, c->st));
+      CK(launch_cfg_ddim_prev(eps + (size_t)p * nimg * 4 * E, lp, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lp, c->st));
     }
     CKP(apply_local_blend(c, lat, i));
   }

@@ -40,12 +40,12 @@ int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to,
 // eps: [nimg][2R][E] (first R rows unconditional, next R conditional); x: [nimg][R][E]
 //   e   = eps_u + g * (eps_c - eps_u)
 //   prev = ddim(x, e)
-//   target != null  (offset_calculate):  loss = target[img] - prev ; offset_out = loss ; x_out = prev + loss
+//   target != null  (offset_calculate):  loss = (target[img] - prev) * oscale ; offset_out = loss ; x_out = prev + loss
 //   else noise_loss != null            :  x_out = prev + noise_loss[img][r]  for r < offset_rows, prev otherwise
 __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float* __restrict__ x, int nimg, int R, size_t E, float g,
                                      float sa_f, float sb_f, float sa_t, float sb_t, const float* __restrict__ noise_loss,
-                                     int offset_rows, const float* __restrict__ target, float* __restrict__ offset_out,
-                                     float* __restrict__ x_out) {
+                                     int offset_rows, const float* __restrict__ target, float oscale,
+                                     float* __restrict__ offset_out, float* __restrict__ x_out) {
   const size_t total = (size_t)nimg * R * E;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t e_idx = i % E;
@@ -58,7 +58,9 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
     float prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
     float outv = prev;
     if (target) {
-      float loss = __fsub_rn(target[(size_t)img * E + e_idx], prev);
+      // loss = (x*_{t-1} - prev) * scale: scale is 1 on the paper's path, `scale` / 0-or-1 in the not_full / skip_step ablations
+      // (inversion.py:491-492, 512-515)
+      float loss = __fmul_rn(__fsub_rn(target[(size_t)img * E + e_idx], prev), oscale);
       offset_out[i] = loss;
       outv = __fadd_rn(prev, loss);
     } else if (noise_loss && r < offset_rows) {
@@ -69,15 +71,15 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
 }
 
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale, float a_t,
-                         float a_prev, const float* noise_loss, int offset_rows, const float* target, float* offset_out,
-                         float* x_out, hipStream_t st) {
+                         float a_prev, const float* noise_loss, int offset_rows, const float* target, float offset_scale,
+                         float* offset_out, float* x_out, hipStream_t st) {
   float sa_f = sqrtf(a_t), sb_f = sqrtf(1.0f - a_t), sa_t = sqrtf(a_prev), sb_t = sqrtf(1.0f - a_prev);
   size_t total = (size_t)nimg * rows_per_img * row_elems;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   cfg_ddim_prev_kernel<<<blocks, 256, 0, st>>>(eps, x, nimg, rows_per_img, row_elems, gscale, sa_f, sb_f, sa_t, sb_t, noise_loss,
-                                               offset_rows, target, offset_out, x_out);
+                                               offset_rows, target, offset_scale, offset_out, x_out);
   return (int)hipGetLastError();
 }
 

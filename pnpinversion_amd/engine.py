@@ -259,17 +259,36 @@ class NativeEngine:
         self._keep = (z0, ctx, ts)
         return out
 
-    def offset_calculate(self, ddim_latents, context4, timesteps, guidance_scale):
+    @staticmethod
+    def _scales(offset_scale, n):
+        """None | float | sequence[n] -> (keep-alive array, float* or None): per-step factor on the direct-inversion offset"""
+        if offset_scale is None:
+            return None, None
+        sc = np.ascontiguousarray(np.broadcast_to(np.asarray(offset_scale, dtype=np.float32), (n,)))
+        return sc, sc.ctypes.data_as(C.POINTER(C.c_float))
+
+    def ddim_invert_cfg(self, z0, ctx_uncond, ctx_cond, timesteps, guidance_scale):
+        """DDIM inversion under classifier-free guidance (inversion.py:334-347) -> [steps+1, nimg, 4, h, w]"""
+        z0, cu, cc = self._f32(z0), self._f32(ctx_uncond), self._f32(ctx_cond)
+        n, nimg = len(timesteps), z0.shape[0]
+        out = torch.empty(n + 1, *z0.shape, device=self.device)
+        ts, tsp = self._ts(timesteps)
+        self._call("pnpi_ddim_invert_cfg", _p(z0), nimg, _p(cu), _p(cc), float(guidance_scale), n, tsp, _p(out))
+        self._keep = (z0, cu, cc, ts)
+        return out
+
+    def offset_calculate(self, ddim_latents, context4, timesteps, guidance_scale, offset_scale=None):
         lat, ctx = self._f32(ddim_latents), self._f32(context4)
         n = len(timesteps)
         nimg = lat.shape[1]
         out = torch.empty(n, nimg, 2, *lat.shape[2:], device=self.device)
         ts, tsp = self._ts(timesteps)
-        self._call("pnpi_offset_calculate", _p(lat), nimg, _p(ctx), n, tsp, float(guidance_scale), _p(out))
-        self._keep = (lat, ctx, ts)
+        sc, scp = self._scales(offset_scale, n)
+        self._call("pnpi_offset_calculate", _p(lat), nimg, _p(ctx), n, tsp, float(guidance_scale), scp, _p(out))
+        self._keep = (lat, ctx, ts, sc)
         return out
 
-    def direct_edit(self, ddim_latents, context4, ctrls_per_pass, timesteps, guidance_scale, offset_rows=1):
+    def direct_edit(self, ddim_latents, context4, ctrls_per_pass, timesteps, guidance_scale, offset_rows=1, offset_scale=None):
         """offset_calculate + len(ctrls_per_pass) guidance-forward passes in lock step (pnpi_direct_edit).
         ctrls_per_pass: list (passes) of None | list[ControllerTables | None] (images).  -> (noise_loss, latents[npass])"""
         lat, ctx = self._f32(ddim_latents), self._f32(context4)
@@ -284,8 +303,9 @@ class NativeEngine:
         nl = torch.empty(n, nimg, 2, *lat.shape[2:], device=self.device)
         out = torch.empty(npass, nimg, 2, *lat.shape[2:], device=self.device)
         ts, tsp = self._ts(timesteps)
-        self._call("pnpi_direct_edit", _p(lat), nimg, _p(ctx), npass, arr, int(offset_rows), n, tsp, float(guidance_scale), _p(nl), _p(out))
-        self._keep = (lat, ctx, ts, arr, flat)
+        sc, scp = self._scales(offset_scale, n)
+        self._call("pnpi_direct_edit", _p(lat), nimg, _p(ctx), npass, arr, int(offset_rows), n, tsp, float(guidance_scale), scp, _p(nl), _p(out))
+        self._keep = (lat, ctx, ts, arr, flat, sc)
         return nl, out
 
     def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1):

@@ -49,3 +49,44 @@ def direct_inversion_p2p_guidance_forward_add_target(model, prompt, controller, 
                                                      guidance_scale=7.5, generator=None, noise_loss_list=None, add_offset=True):
     """p2p_guidance_forward.py:119-132,175-213: the offset is added to both branches."""
     return _run(model, prompt, controller, latent, num_inference_steps, guidance_scale, generator, noise_loss_list, add_offset, 2)
+
+
+def _constant_uncond(uncond_embeddings):
+    """The native loop takes one context for the whole loop.  ddim+p2p and negative-prompt inversion hand over the same
+    embedding for every step (inversion.py:226, 98); a genuinely per-step list (null-text optimisation) is not built."""
+    first = uncond_embeddings[0]
+    for u in uncond_embeddings[1:]:
+        if u is not first and not torch.equal(u, first):
+            raise NotImplementedError("per-step unconditional embeddings (null-text inversion) are not built (SURVEY 8f rank 4)")
+    return first
+
+
+@torch.no_grad()
+def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 50, guidance_scale=7.5, generator=None, latent=None,
+                         uncond_embeddings=None):
+    """models/p2p/p2p_guidance_forward.py:21-62: the plain Prompt-to-Prompt CFG loop (no direct-inversion offset); one or two
+    prompts; `uncond_embeddings` = per-step replacement of the "" embedding."""
+    batch_size = len(prompt)
+    if batch_size not in (1, 2):
+        raise NotImplementedError("the native loop handles one prompt or one (source, target) pair")
+    register_attention_control(model, controller)
+    height = width = model.engine.cfg.sample_size * model.engine.cfg.vae_scale
+    tok = model.tokenizer
+    text_input = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
+    text = model.text_encoder(text_input.input_ids.to(model.device))[0]
+    if uncond_embeddings is None:
+        uncond_input = tok([""] * batch_size, padding="max_length", max_length=text_input.input_ids.shape[-1], return_tensors="pt")
+        uncond = model.text_encoder(uncond_input.input_ids.to(model.device))[0]
+    else:
+        uncond = _constant_uncond(uncond_embeddings).to(text.device).expand(*text.shape)
+    latent, latents = init_latent(latent, model, height, width, generator, batch_size)
+    model.scheduler.set_timesteps(num_inference_steps)
+    if batch_size == 1:   # the kernel batch is [unc_a, unc_b, cond_a, cond_b]: run the single prompt as both rows of a pair
+        uncond, text = uncond.expand(2, *uncond.shape[1:]), text.expand(2, *text.shape[1:])
+    context = torch.cat([uncond, text])
+    tables = controller.tables() if controller is not None and hasattr(controller, "tables") else None
+    out = model.engine.edit_loop(latent.reshape(1, *latent.shape[-3:]), context[None], None, [tables] if tables is not None else None,
+                                 model.scheduler.timesteps.numpy(), guidance_scale)
+    if controller is not None and hasattr(controller, "cur_step"):
+        controller.cur_step += num_inference_steps
+    return out[0][:batch_size], latent

@@ -1,16 +1,21 @@
 """P2PEditor with the constructor / call signature of the reference's models/p2p_editor.py:12-45, on the native pipeline.
 
-Implemented method strings (Appendix D of SURVEY.md): "directinversion+p2p" (the hot path),
-"ablation_directinversion_add-target+p2p" / "...add-source+p2p".  Any other string raises the reference's
+Implemented method strings (Appendix D of SURVEY.md; models/p2p_editor.py:46-135): "directinversion+p2p" (the hot path) and
+every loop variant of it that needs no new kernel -- "ddim+p2p", "negative-prompt-inversion+p2p", the 20
+"directinversion+p2p_guidance_<inv>_<fwd>" strings, "ablation_directinversion_{04,08}+p2p",
+"ablation_directinversion_interval_{2,5,10,24,49}+p2p", "ablation_directinversion_add-target+p2p" / "...add-source+p2p".
+The methods that optimise through the UNet (null-text, null-latent) or need the proximal-guidance select are reference
+method strings that raise NotImplementedError naming what is missing; any other string raises the reference's
 NotImplementedError(f"No edit method named {edit_method}") (models/p2p_editor.py:134-135)."""
 import numpy as np
 from PIL import Image
 
 from .config import SD1
 from .p2p.attention_control import AttentionStore, make_controller
-from .p2p.inversion import DirectInversion
+from .p2p.inversion import DirectInversion, NegativePromptInversion, NullInversion
 from .p2p.p2p_guidance_forward import (direct_inversion_p2p_guidance_forward,
-                                       direct_inversion_p2p_guidance_forward_add_target)
+                                       direct_inversion_p2p_guidance_forward_add_target, p2p_guidance_forward)
+from .p2p.proximal_guidance_forward import proximal_guidance_forward
 from .p2p.attention_control import register_attention_control
 from .pipeline import NativePipeline
 from .utils.utils import image2latent, latent2image, load_512, txt_draw
@@ -40,22 +45,46 @@ class P2PEditor:
     def __call__(self, edit_method, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None, quantile=0.7,
                  use_reconstruction_guidance=False, recon_t=400, recon_lr=0.1, cross_replace_steps=0.4, self_replace_steps=0.6,
                  blend_word=None, eq_params=None, is_replace_controller=False, use_inversion_guidance=False, dilate_mask=1):
+        kw = dict(guidance_scale=guidance_scale, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                  blend_word=blend_word, eq_params=eq_params, is_replace_controller=is_replace_controller)
         if edit_method == "directinversion+p2p":
-            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale,
-                                                   cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
-                                                   blend_word=blend_word, eq_params=eq_params,
-                                                   is_replace_controller=is_replace_controller)
+            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, **kw)
+        if edit_method == "ddim+p2p":
+            return self.edit_image_ddim(image_path, prompt_src, prompt_tar, **kw)
+        if edit_method == "negative-prompt-inversion+p2p":
+            return self.edit_image_negative_prompt_inversion(image_path, prompt_src, prompt_tar, proximal=None, **kw)
+        if edit_method.startswith("directinversion+p2p_guidance_"):
+            table = {"0": 0, "1": 1, "25": 2.5, "5": 5, "75": 7.5}          # models/p2p_editor.py:78-88
+            parts = edit_method.split("_")
+            if len(parts) == 4 and parts[-2] in table and parts[-1] in ("1", "5", "25", "75"):
+                kw.pop("guidance_scale")
+                return self.edit_image_directinversion_vary_guidance_scale(image_path, prompt_src, prompt_tar,
+                                                                           inverse_guidance_scale=table[parts[-2]],
+                                                                           forward_guidance_scale=table[parts[-1]], **kw)
+        if edit_method in ("ablation_directinversion_08+p2p", "ablation_directinversion_04+p2p"):
+            scale = float(edit_method.split("+")[0].split("_")[-1]) / 10
+            return self.edit_image_directinversion_not_full(image_path, prompt_src, prompt_tar, scale=scale, **kw)
+        if edit_method in ("ablation_directinversion_interval_2+p2p", "ablation_directinversion_interval_5+p2p",
+                           "ablation_directinversion_interval_10+p2p", "ablation_directinversion_interval_24+p2p",
+                           "ablation_directinversion_interval_49+p2p"):
+            skip_step = int(edit_method.split("+")[0].split("_")[-1])
+            return self.edit_image_directinversion_skip_step(image_path, prompt_src, prompt_tar, skip_step=skip_step, **kw)
         if edit_method in ("ablation_directinversion_add-target+p2p", "ablation_directinversion_add-source+p2p"):
-            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale,
-                                                   cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
-                                                   blend_word=blend_word, eq_params=eq_params,
-                                                   is_replace_controller=is_replace_controller, add_target=True)
+            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, add_target=True, **kw)
+        if edit_method in ("null-text-inversion+p2p", "null-text-inversion+p2p_a800", "null-text-inversion+p2p_3090",
+                           "ablation_null-text-inversion_single_branch+p2p", "null-text-inversion+proximal-guidance",
+                           "ablation_null-latent-inversion+p2p"):
+            raise NotImplementedError(f"{edit_method}: optimises through the UNet (backward pass); not built (SURVEY 8f rank 4)")
+        if edit_method == "negative-prompt-inversion+proximal-guidance":
+            raise NotImplementedError(f"{edit_method}: proximal guidance (quantile select + dilate) is not built (SURVEY 8f rank 3)")
         raise NotImplementedError(f"No edit method named {edit_method}")
 
     def edit_image_directinversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
                                    self_replace_steps=0.6, blend_word=None, eq_params=None, is_replace_controller=False,
-                                   add_target=False, return_stages=False):
-        """models/p2p_editor.py:415-479"""
+                                   add_target=False, return_stages=False, inverse_guidance_scale=None, offset_scale=None):
+        """models/p2p_editor.py:415-479; with the keyword-only knobs also :481-548 (vary guidance: CFG inversion at
+        inverse_guidance_scale, everything else at guidance_scale), :707-773 (not_full: offset_scale = scale) and :775-840
+        (skip_step: offset_scale = per-step 0/1 list)."""
         forward = direct_inversion_p2p_guidance_forward_add_target if add_target else direct_inversion_p2p_guidance_forward
         image_gt = load_512(image_path)
         side = self.ldm_stable.engine.cfg.sample_size * self.ldm_stable.engine.cfg.vae_scale
@@ -65,8 +94,15 @@ class P2PEditor:
         null_inversion = DirectInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
         if self.lockstep and self.ldm_stable.engine.max_unet_rows >= 12:
             return self._edit_lockstep(null_inversion, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
-                                       self_replace_steps, blend_word, eq_params, is_replace_controller, add_target, return_stages, side)
-        _, _, x_stars, noise_loss_list = null_inversion.invert(image_gt=image_gt, prompt=prompts, guidance_scale=guidance_scale)
+                                       self_replace_steps, blend_word, eq_params, is_replace_controller, add_target, return_stages, side,
+                                       inverse_guidance_scale, offset_scale)
+        null_inversion.init_prompt(prompts)
+        register_attention_control(self.ldm_stable, None)
+        if inverse_guidance_scale is None:
+            _, x_stars = null_inversion.ddim_inversion(image_gt)
+        else:
+            _, x_stars = null_inversion.ddim_with_guidance_scale_inversion(image_gt, inverse_guidance_scale)
+        noise_loss_list = null_inversion._offsets(x_stars, guidance_scale, offset_scale)
         x_t = x_stars[-1]
         controller = AttentionStore()
         reconstruct_latent, x_t = forward(model=self.ldm_stable, prompt=prompts, controller=controller, noise_loss_list=noise_loss_list,
@@ -88,9 +124,83 @@ class P2PEditor:
                                latents=latents, reconstruct_image=reconstruct_image, edited_image=images[-1])
         return panel
 
+    def edit_image_directinversion_vary_guidance_scale(self, image_path, prompt_src, prompt_tar, inverse_guidance_scale=1,
+                                                       forward_guidance_scale=7.5, **kw):
+        """models/p2p_editor.py:481-548"""
+        return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=forward_guidance_scale,
+                                               inverse_guidance_scale=inverse_guidance_scale, **kw)
+
+    def edit_image_directinversion_not_full(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, scale=1., **kw):
+        """models/p2p_editor.py:707-773"""
+        return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale,
+                                               offset_scale=float(scale), **kw)
+
+    def edit_image_directinversion_skip_step(self, image_path, prompt_src, prompt_tar, skip_step, guidance_scale=7.5, **kw):
+        """models/p2p_editor.py:775-840"""
+        sc = [1.0 if i % skip_step == 0 else 0.0 for i in range(self.num_ddim_steps)]
+        return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale, offset_scale=sc, **kw)
+
+    def _plain_p2p(self, forward, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
+                   self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages):
+        """Shared tail of edit_image_ddim / edit_image_negative_prompt_inversion (p2p_editor.py:158-196, 351-411): an
+        AttentionStore reconstruction of the source prompt alone, then the controlled pair, both without offsets."""
+        x_t = x_stars[-1]
+        reconstruct_latent, x_t = forward(model=self.ldm_stable, prompt=[prompt_src], controller=AttentionStore(), latent=x_t,
+                                          guidance_scale=guidance_scale, generator=None, uncond_embeddings=uncond_embeddings)
+        reconstruct_image = latent2image(model=self.ldm_stable.vae, latents=reconstruct_latent)[0]
+        controller = make_controller(pipeline=self.ldm_stable, prompts=[prompt_src, prompt_tar],
+                                     is_replace_controller=is_replace_controller,
+                                     cross_replace_steps={"default_": cross_replace_steps}, self_replace_steps=self_replace_steps,
+                                     blend_words=blend_word, equilizer_params=eq_params, num_ddim_steps=self.num_ddim_steps,
+                                     device=self.device)
+        latents, _ = forward(model=self.ldm_stable, prompt=[prompt_src, prompt_tar], controller=controller, latent=x_t,
+                             guidance_scale=guidance_scale, generator=None, uncond_embeddings=uncond_embeddings)
+        images = latent2image(model=self.ldm_stable.vae, latents=latents)
+        image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
+        panel = Image.fromarray(np.concatenate((image_instruct, image_gt, reconstruct_image, images[-1]), axis=1))
+        if return_stages:
+            return panel, dict(x_stars=x_stars, reconstruct_latent=reconstruct_latent, latents=latents)
+        return panel
+
+    def _load(self, image_path):
+        image_gt = load_512(image_path)
+        side = self.ldm_stable.engine.cfg.sample_size * self.ldm_stable.engine.cfg.vae_scale
+        if side != 512:   # reduced test configurations only
+            image_gt = np.array(Image.fromarray(image_gt).resize((side, side)))
+        return image_gt, side
+
+    def edit_image_ddim(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
+                        self_replace_steps=0.6, blend_word=None, eq_params=None, is_replace_controller=False, return_stages=False):
+        """models/p2p_editor.py:137-197: DDIM inversion of the source prompt, then plain Prompt-to-Prompt (no correction)."""
+        image_gt, side = self._load(image_path)
+        self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
+        inv = NullInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
+        _, _, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, guidance_scale=guidance_scale,
+                                                      num_inner_steps=0)
+        fwd = lambda **k: p2p_guidance_forward(num_inference_steps=self.num_ddim_steps, **k)   # noqa: E731
+        return self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
+                               self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
+
+    def edit_image_negative_prompt_inversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None,
+                                             quantile=0.7, use_reconstruction_guidance=False, recon_t=400, recon_lr=0.1, npi_interp=0,
+                                             cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=None, eq_params=None,
+                                             is_replace_controller=False, use_inversion_guidance=False, dilate_mask=1,
+                                             return_stages=False):
+        """models/p2p_editor.py:324-413 with proximal=None (the +p2p method): the source prompt's embedding replaces "" """
+        if proximal is not None:
+            raise NotImplementedError("proximal guidance is not built (SURVEY 8f rank 3)")
+        image_gt, side = self._load(image_path)
+        self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
+        inv = NegativePromptInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
+        _, _, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, npi_interp=npi_interp)
+        fwd = lambda **k: proximal_guidance_forward(edit_stage=True, prox=None, num_inference_steps=self.num_ddim_steps, **k)   # noqa: E731
+        return self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
+                               self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
+
     @torch.no_grad()
     def _edit_lockstep(self, inv, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps, self_replace_steps,
-                       blend_word, eq_params, is_replace_controller, add_target, return_stages, side):
+                       blend_word, eq_params, is_replace_controller, add_target, return_stages, side, inverse_guidance_scale=None,
+                       offset_scale=None):
         """Same phases as models/p2p_editor.py:415-479, re-scheduled: after the 50 B=1 inversion steps, offset_calculate
         (inversion.py:375-391), the AttentionStore reconstruction pass and the edit pass (p2p_guidance_forward.py:135-173) walk
         the same 50 timesteps and only exchange noise_loss[i] at step i, so they run as ONE 12-row UNet launch per step."""
@@ -98,14 +208,18 @@ class P2PEditor:
         model.scheduler.set_timesteps(self.num_ddim_steps)
         inv.init_prompt(prompts)
         register_attention_control(model, None)
-        _, x_stars = inv.ddim_inversion(image_gt)
+        if inverse_guidance_scale is None:
+            _, x_stars = inv.ddim_inversion(image_gt)
+        else:
+            _, x_stars = inv.ddim_with_guidance_scale_inversion(image_gt, inverse_guidance_scale)
         controller = make_controller(pipeline=model, prompts=prompts, is_replace_controller=is_replace_controller,
                                      cross_replace_steps={"default_": cross_replace_steps}, self_replace_steps=self_replace_steps,
                                      blend_words=blend_word, equilizer_params=eq_params, num_ddim_steps=self.num_ddim_steps,
                                      device=self.device)
         register_attention_control(model, controller)
         nl, lats = model.engine.direct_edit(torch.stack(x_stars), inv.context[None], [None, [controller.tables()]],
-                                            model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1)
+                                            model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1,
+                                            offset_scale=offset_scale)
         controller.cur_step += self.num_ddim_steps
         noise_loss_list = [nl[i, 0] for i in range(nl.shape[0])]
         reconstruct_latent, latents = lats[0, 0], lats[1, 0]

@@ -326,13 +326,13 @@ def test_step_kernels_bit_exact(ctx):
         off = torch.empty(2, 4, 16, 16, device=DEV)
         xo = torch.empty(2, 4, 16, 16, device=DEV)
         td = target.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), ptr(off), ptr(xo))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), 1.0, ptr(off), ptr(xo))
         assert torch.equal(off.cpu(), loss) and torch.equal(xo.cpu(), cur), t
         # guidance step with noise_loss on the first row only (p2p_guidance_forward.py:110-114)
         nl = torch.randn(2, 4, 16, 16, generator=g)
         ref2 = torch.cat((prev[:1] + nl[:1], prev[1:]))
         nld = nl.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, None, ptr(xo))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, 1.0, None, ptr(xo))
         assert torch.equal(xo.cpu(), ref2), t
         # DDIMSchedulerDev.step == prev_step
         ctx.call("pnpi_ddim_prev_step", ptr(ed), t, 20, ptr(xd), x.numel(), ptr(out))

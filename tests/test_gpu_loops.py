@@ -221,3 +221,66 @@ def test_batched_images_match_single_image_calls():
     with pytest.raises(ValueError, match="max_unet_rows"):
         ed.edit_images_directinversion([img0] * 3, src + src[:1], tgt + tgt[:1])
     pipe.engine.close()
+
+
+VARIANTS = ["ddim+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5", "ablation_directinversion_04+p2p",
+            "ablation_directinversion_interval_2+p2p", "ablation_directinversion_add-target+p2p"]
+
+
+@pytest.mark.parametrize("lockstep", [True, False])
+@pytest.mark.parametrize("method", VARIANTS)
+def test_editor_method_variants_against_reference_golden(small64, method, lockstep):
+    """The other P2PEditor method strings that share the loop, against what the reference's own
+    P2PEditor.__call__ produced for them (tests/golden/e2e_variants.npz; same image, prompts, weights as e2e_refine)."""
+    v = np.load(os.path.join(GOLD, "e2e_variants.npz"))
+    steps = int(v["steps"])
+    ed = P2PEditor([method], "cuda", num_ddim_steps=steps, pipeline=small64)
+    ed.lockstep = lockstep
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    src, tgt = str(v["src"]), str(v["tgt"])
+    w0, w1 = [str(x) for x in v["blend"]]
+    kw = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+              eq_params={"words": (w1,), "values": (2,)}, is_replace_controller=False)
+    panel = ed(method, img, src, tgt, **kw)
+    assert panel.size == (2048, 512)
+    small = np.array(panel)[::4, 1536::4]
+    assert np.abs(small.astype(np.int32) - v[method + "/edited_image_small"].astype(np.int32)).mean() < 4.0
+    # stage outputs through the same code path the dispatcher took
+    if method == "ddim+p2p":
+        _, st = ed.edit_image_ddim(img, src, tgt, return_stages=True, **kw)
+    elif method == "negative-prompt-inversion+p2p":
+        _, st = ed.edit_image_negative_prompt_inversion(img, src, tgt, return_stages=True, **kw)
+    else:
+        extra = {"directinversion+p2p_guidance_25_5": dict(inverse_guidance_scale=2.5),
+                 "ablation_directinversion_04+p2p": dict(offset_scale=0.4),
+                 "ablation_directinversion_interval_2+p2p": dict(offset_scale=[1.0 if i % 2 == 0 else 0.0 for i in range(steps)]),
+                 "ablation_directinversion_add-target+p2p": dict(add_target=True)}[method]
+        if method.startswith("directinversion+p2p_guidance"):
+            kw["guidance_scale"] = 5.0
+        _, st = ed.edit_image_directinversion(img, src, tgt, return_stages=True, **extra, **kw)
+        if method + "/x_stars" in v:
+            xs = torch.stack([x.cpu() for x in st["x_stars"]])
+            assert rel(xs, v[method + "/x_stars"]) < 6e-3, rel(xs, v[method + "/x_stars"])
+        if method + "/noise_loss" in v:
+            nl = torch.stack([x.cpu() for x in st["noise_loss_list"]])
+            ref_nl = torch.from_numpy(v[method + "/noise_loss"])
+            assert rel(nl, ref_nl) < 2e-2, rel(nl, ref_nl)
+            if method.endswith("interval_2+p2p"):
+                assert nl[1].abs().max().item() == 0.0
+    ref = torch.from_numpy(v[method + "/edited_latents"])
+    r, frac = masked_rel(st["latents"], ref, tol_frac=0.01)
+    assert frac <= 0.01 and r < 2.5e-2, (method, r, frac)
+    rec = st["reconstruct_latent"].cpu()
+    ref_rec = torch.from_numpy(v[method + "/reconstruct_latent"])
+    assert rel(rec[:1], ref_rec[:1]) < 2.5e-2, rel(rec[:1], ref_rec[:1])
+
+
+def test_unbuilt_reference_methods_say_so(small64):
+    ed = P2PEditor(["x"], "cuda", num_ddim_steps=2, pipeline=small64)
+    img = np.zeros((64, 64, 3), np.uint8)
+    for m in ("null-text-inversion+p2p", "negative-prompt-inversion+proximal-guidance", "ablation_null-latent-inversion+p2p"):
+        with pytest.raises(NotImplementedError, match="not built"):
+            ed(m, img, "a", "b")
+    with pytest.raises(NotImplementedError, match="No edit method named"):
+        ed("directinversion+p2p_guidance_9_9", img, "a", "b")

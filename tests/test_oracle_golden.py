@@ -114,3 +114,57 @@ def test_loops_and_controllers_match_reference(name):
     assert rel(out, g["edited_latents"]) < 5e-5, rel(out, g["edited_latents"])
     # Note D of SURVEY.md: the source branch reproduces x*_0
     assert rel(out[0], x_stars[0][0]) < 1e-4
+
+
+VARIANTS = ["ddim+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5", "ablation_directinversion_04+p2p",
+            "ablation_directinversion_interval_2+p2p", "ablation_directinversion_add-target+p2p"]
+
+
+@pytest.mark.parametrize("method", VARIANTS)
+def test_loop_variants_match_reference(method):
+    """The other method strings of the reference's P2PEditor that share this loop (tests/golden/e2e_variants.npz, produced by the
+    reference's own P2PEditor.__call__): the oracle's loops with the variant's one knob turned."""
+    g, v = load("e2e_refine.npz"), load("e2e_variants.npz")
+    cfg, steps = SMALL64, int(v["steps"])
+    usd = weights.unet_state_dict(cfg, 2)
+    ctx = torch.from_numpy(g["context"]).float()                 # [unc, unc, cond_src, cond_tgt]
+    x_stars = torch.from_numpy(g["x_stars"])
+    ac_, ts = po.alphas_cumprod(), po.make_timesteps(steps)
+
+    def unet_fn(lat, t, c, hook):
+        with torch.no_grad():
+            return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    ref_edit = torch.from_numpy(v[method + "/edited_latents"])
+    ctrl = po.EditController(32, _tables_from_product(g, steps))
+    if method in ("ddim+p2p", "negative-prompt-inversion+p2p"):
+        # plain P2P on the DDIM latents: "" embedding (ddim) or the source prompt's embedding (NPI) as the unconditional rows
+        c4 = ctx if method == "ddim+p2p" else torch.cat([ctx[2:3], ctx[2:3], ctx[2:]])
+        out = po.guidance_forward(unet_fn, x_stars[-1], c4, None, ctrl, ts, ac_, ac_[0], 7.5)
+        assert rel(out, ref_edit) < 5e-5, rel(out, ref_edit)
+        return
+    gs, scale, rows = 7.5, None, 1
+    xs = [x for x in x_stars]
+    if method == "directinversion+p2p_guidance_25_5":
+        gs = 5.0
+        lat = po.ddim_loop_cfg(unet_fn, x_stars[0], ctx[0:1], ctx[2:3], ts, ac_, ac_[0], 2.5)
+        ref_xs = torch.from_numpy(v[method + "/x_stars"])
+        assert rel(torch.stack(lat), ref_xs) < 2e-5
+        xs = [x for x in ref_xs]
+    elif method == "ablation_directinversion_04+p2p":
+        scale = 0.4
+    elif method == "ablation_directinversion_interval_2+p2p":
+        scale = [1.0 if i % 2 == 0 else 0.0 for i in range(steps)]
+    else:
+        rows = 2
+    if method + "/noise_loss" in v:
+        nl = po.offset_calculate(unet_fn, xs, ctx, ts, ac_, ac_[0], gs, offset_scale=scale)
+        ref_nl = torch.from_numpy(v[method + "/noise_loss"])
+        s = xs[0].norm().item() / xs[0].numel() ** 0.5
+        assert (torch.stack(nl) - ref_nl).abs().max().item() < 5e-5 * max(1.0, s)
+        if scale is not None and not isinstance(scale, float):
+            assert ref_nl[1].abs().max().item() == 0.0           # the skipped step's offset is exactly zero
+    else:
+        ref_nl = torch.from_numpy(g["noise_loss"])
+    out = po.guidance_forward(unet_fn, xs[-1], ctx, [x for x in ref_nl], ctrl, ts, ac_, ac_[0], gs, offset_rows=rows)
+    assert rel(out, ref_edit) < 5e-5, rel(out, ref_edit)
