@@ -14,6 +14,10 @@ LIB = os.path.join(CSRC, "libpnpi.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "step.hip", "api.hip"]
 HEADERS = ["common.h", "ops.h", "model.h", os.path.join("..", "..", "include", "pnpi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-value"]
+# Per-file flags.  step.hip: the reference rounds every multiply / add separately (no FMA contraction).  attn.hip: keep the MFMA
+# accumulators in VGPRs (gfx950's unified file) -- the softmax between the two MFMAs is VALU work on the S accumulators, and in
+# AGPR form every element costs a v_accvgpr_read (and a write to clear it): 96 of ~300 VALU instructions per 64-key tile.
+EXTRA = {"step.hip": ["-ffp-contract=off"], "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -43,7 +47,9 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        extra = ["-ffp-contract=off"] if os.path.basename(s) == "step.hip" else []
+        extra = list(EXTRA.get(os.path.basename(s), []))
+        if os.path.basename(s)[:-4] in os.environ.get("PNPI_VGPR_FORM", "").split(","):   # experiments: PNPI_VGPR_FORM=gemm
+            extra += ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
         cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
