@@ -227,7 +227,7 @@ def main():
         }
         if batched is not None:
             out["batched"] = batched
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, see cpu_baseline)
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
     if dist is not None:

@@ -1,6 +1,8 @@
 """Whole-graph parity of the native UNet / VAE against the CPU oracle (oracle/sd_oracle.py) on identical seeded weights.
 Stated tolerances (fp16 activations / fp32 accumulation vs fp32 oracle), cf. SURVEY.md 8(d):
   UNet single forward: rel-L2(eps) <= 4e-3;  VAE encode mean: rel-L2 <= 4e-3;  VAE decode: rel-L2 <= 6e-3, |pixel diff| mean <= 2/255."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -105,3 +107,34 @@ def test_unet_and_vae_sd1_full_width():
     assert rel(eng.vae_encode(img), ref_m) < 4e-3
     assert rel(eng.vae_decode(z), ref_d) < 6e-3
     eng.close()
+
+
+def test_weight_arena_broadcast_over_rccl_world1():
+    """The one collective of the path (RCCL broadcast of the packed weight arena, distributed.py) on a real device buffer:
+    a world-size-1 NCCL group is all a 1-GPU box allows, but it exercises the zero-copy arena view, the chunking and the RCCL
+    call itself; the world-size-2 logic runs on gloo in tests/test_distributed_cpu.py."""
+    import torch.distributed as dist
+    from pnpinversion_amd.config import TINY16
+    from pnpinversion_amd.distributed import arena_tensor, broadcast_weights
+    from pnpinversion_amd.engine import NativeEngine
+    from pnpinversion_amd import weights
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng = NativeEngine(TINY16, max_unet_rows=2, max_vae_images=1)
+        eng.load_state_dict(weights.unet_state_dict(TINY16, 3), weights.vae_state_dict(TINY16, 3))
+        lat = torch.randn(2, 4, 16, 16, device="cuda")
+        ctx = torch.randn(2, 77, TINY16.cross_dim, device="cuda")
+        before = eng.unet(lat, 300, ctx).clone()
+        t = arena_tensor(eng)
+        assert t.is_cuda and t.dtype == torch.uint8 and t.numel() == eng.weight_arena()[1] and t.data_ptr() == eng.weight_arena()[0]
+        snap = t.clone()
+        n = broadcast_weights(eng, src=0)
+        assert n == t.numel() and torch.equal(t, snap)
+        assert torch.equal(eng.unet(lat, 300, ctx), before)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
