@@ -73,7 +73,8 @@ typedef struct {
  * AttentionStore (:214), AttentionReplace (:301), AttentionRefine (:317), AttentionReweight (:338) and LocalBlend (:95).
  * All pointers are HOST pointers; tables are copied at the call. */
 typedef struct {
-  int kind;                        /* 0 = none / AttentionStore (no effect on the output), 1 = edit */
+  int kind;                        /* 0 = none / AttentionStore (no effect on the output), 1 = Prompt-to-Prompt edit,
+                                      2 = MasaCtrl mutual self-attention (models/masactrl/masactrl.py:14-72) */
   int n_alpha_rows;                /* rows of cross_alpha (num_steps + 1 = 51) */
   const float* cross_alpha_host;   /* [n_alpha_rows][77]  get_time_words_attention_alpha, utils/utils.py:117-135 */
   const float* mapper_host;        /* [77][77] source-token w -> target-token j weights (Replace: seq_aligner.py:152-185;
@@ -86,6 +87,9 @@ typedef struct {
   int lb_start;                    /* start_blend = int(0.2 * steps) = 10 */
   float lb_threshold;              /* 0.3 */
   const float* lb_alpha_host;      /* [2][77] alpha_layers one-hot rows (src prompt, tgt prompt) */
+  int masa_start_step;             /* kind 2: steps >= start_step (4) ...                   masactrl.py:36,61 */
+  int masa_start_layer;            /* ... and transformer blocks >= start_layer (10, execution order 0..15): the target rows'
+                                      self-attention reads K and V of the source row of their CFG half (masactrl.py:63-69) */
 } pnpi_ctrl_desc;
 
 typedef struct {

@@ -13,6 +13,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_variants.npz     the reference's P2PEditor run on six more method strings that share the loop (ddim+p2p,
                        negative-prompt-inversion+p2p, a vary-guidance, a not_full, a skip_step and the add-target ablation):
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
+  e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
 """
 import json
 import os
@@ -222,10 +223,75 @@ def variants(steps=2):
     np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
 
 
+def masactrl(steps=6, start_step=2, start_layer=10):
+    """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
+    self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
+    editor relies on that default for its second call (run_editing_masactrl.py:118-121); the default is set to `steps` here."""
+    import inspect
+    cfg = SMALL64
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    ed = ref_shim.build_masactrl_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    from models.masactrl.diffuser_utils import MasaCtrlPipeline
+    import models.p2p.inversion as inv
+    params = list(inspect.signature(MasaCtrlPipeline.__call__).parameters.values())
+    names = [p.name for p in params if p.default is not inspect.Parameter.empty]
+    d = list(MasaCtrlPipeline.__call__.__wrapped__.__defaults__) if hasattr(MasaCtrlPipeline.__call__, "__wrapped__") else None
+    fn = MasaCtrlPipeline.__call__.__wrapped__ if d is not None else MasaCtrlPipeline.__call__
+    d = list(fn.__defaults__)
+    d[names.index("num_inference_steps")] = steps
+    fn.__defaults__ = tuple(d)
+    src, tgt = PROMPT_PAIRS[0][0], PROMPT_PAIRS[0][1]
+    img_path = os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")
+    out = {"steps": np.int64(steps), "start_step": np.int64(start_step), "start_layer": np.int64(start_layer), "src": src, "tgt": tgt}
+    for m in ("directinversion+masactrl", "ddim+masactrl"):
+        t0 = time.time()
+        decoded, stages = [], {}
+        orig_l2i = ed.model.latent2image
+        orig_invert = inv.DirectInversion.invert
+        orig_pinv = ed.model.invert
+
+        def l2i_spy(latents, return_type="np"):
+            decoded.append(latents.clone().numpy())
+            return orig_l2i(latents, return_type=return_type)
+
+        def invert_spy(self, *a, **k):
+            r = orig_invert(self, *a, **k)
+            stages["x_stars"] = torch.stack([x.clone() for x in r[2]]).numpy()
+            stages["noise_loss"] = torch.stack([x.clone() for x in r[3]]).numpy()
+            return r
+
+        def pinv_spy(*a, **k):
+            r = orig_pinv(*a, **k)
+            stages["x_stars"] = torch.stack([x.clone() for x in r[1]]).numpy()
+            return r
+
+        ed.model.latent2image = l2i_spy
+        inv.DirectInversion.invert = invert_spy
+        ed.model.invert = pinv_spy
+        try:
+            with ref_shim.cuda_to_cpu(), torch.no_grad():
+                panel = ed(m, img_path, src, tgt, 7.5, step=start_step, layper=start_layer)
+        finally:
+            ed.model.latent2image = orig_l2i
+            inv.DirectInversion.invert = orig_invert
+            ed.model.invert = orig_pinv
+        lat = [x for x in decoded if x.shape[0] in (1, 2) and x.ndim == 4]
+        out[m + "/x_stars"] = stages["x_stars"]
+        if "noise_loss" in stages:
+            out[m + "/noise_loss"] = stages["noise_loss"]
+        out[m + "/fixed_latents"] = lat[-2]
+        out[m + "/masactrl_latents"] = lat[-1]
+        p = np.array(panel)
+        out[m + "/recon_image_small"] = p[::4, 1024:1536:4]
+        out[m + "/edited_image_small"] = p[::4, 1536::4]
+        print("masactrl", m, "%.1fs" % (time.time() - t0), {k: v.shape for k, v in out.items() if k.startswith(m + "/")})
+    np.savez_compressed(os.path.join(OUT, "e2e_masactrl.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["host", "models", "e2e", "variants"]
+    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl"]
     if "host" in which:
         host_tables()
     if "models" in which:
@@ -235,3 +301,5 @@ if __name__ == "__main__":
         e2e("replace", True, False)
     if "variants" in which:
         variants()
+    if "masactrl" in which:
+        masactrl()

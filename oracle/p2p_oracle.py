@@ -161,6 +161,48 @@ class EditController(StoreController):
         return x_t
 
 
+class MasaCtrlEditor:
+    """AttentionBase.__call__ + MutualSelfAttentionControl.forward (models/masactrl/masactrl_utils.py:14-41,
+    masactrl.py:41-69): at steps >= start_step and transformer blocks >= start_layer the self-attention of every row of a CFG
+    half uses K, V of the half's first row."""
+
+    def __init__(self, start_step=4, start_layer=10, num_att_layers=32):
+        self.start_step, self.start_layer, self.num_att_layers = start_step, start_layer, num_att_layers
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+    @staticmethod
+    def _merge(out, heads):          # '(b h) n d -> b n (h d)'
+        bh, n, d = out.shape
+        return out.reshape(bh // heads, heads, n, d).permute(0, 2, 1, 3).reshape(bh // heads, n, heads * d)
+
+    def _attn_batch(self, q, k, v, heads, scale):   # masactrl.py:41-55: all rows' queries against one row's keys / values
+        b = q.shape[0] // heads
+        n, d = q.shape[1], q.shape[2]
+        qq = q.reshape(b, heads, n, d).permute(1, 0, 2, 3).reshape(heads, b * n, d)
+        sim = torch.einsum("hid,hjd->hij", qq, k) * scale
+        out = torch.einsum("hij,hjd->hid", sim.softmax(-1), v)                      # [h, b*n, d]
+        return out.reshape(heads, b, n, d).permute(1, 2, 0, 3).reshape(b, n, heads * d)
+
+    def qkv_editor(self, q, k, v, sim, attn, is_cross, place, heads, scale):
+        if is_cross or self.cur_step < self.start_step or self.cur_att_layer // 2 < self.start_layer:
+            out = self._merge(torch.einsum("bij,bjd->bid", attn, v), heads)
+        else:
+            qu, qc = q.chunk(2)
+            ku, kc = k.chunk(2)
+            vu, vc = v.chunk(2)
+            out = torch.cat([self._attn_batch(qu, ku[:heads], vu[:heads], heads, scale),
+                             self._attn_batch(qc, kc[:heads], vc[:heads], heads, scale)])
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+        return out
+
+    def step_callback(self, x_t):
+        return x_t
+
+
 # ----------------------------------------------------------------------------------------------------- loops
 def ddim_loop(unet_fn, z0, ctx_cond, timesteps, ac, final):
     """DirectInversion.ddim_loop (inversion.py:308-319): B = 1, conditional source embedding only, t ascending."""

@@ -188,3 +188,64 @@ def build_editor(cfg, unet_sd, vae_sd, tokenizer, text_encoder, num_ddim_steps, 
     ed.ldm_stable = h
     ed.scheduler.set_timesteps(num_ddim_steps)
     return ed
+
+
+# ---------------------------------------------------------------------------------------------------------- MasaCtrl
+def _install_fake_vision():
+    """run_editing_masactrl.py / models/masactrl import torchvision (read_image, save_image) and cv2, neither installed here.
+    read_image is the only one the editing path calls: PIL stands in (uint8 CHW tensor, as torchvision returns)."""
+    if "torchvision" in sys.modules and getattr(sys.modules["torchvision"], "_pnpi_fake", False):
+        return
+    tv = types.ModuleType("torchvision")
+    tv._pnpi_fake = True
+    io = types.ModuleType("torchvision.io")
+    ut = types.ModuleType("torchvision.utils")
+
+    def read_image(path):
+        from PIL import Image
+        arr = np.array(Image.open(path).convert("RGB")) if isinstance(path, str) else np.asarray(path)
+        return torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1)
+
+    io.read_image = read_image
+    ut.save_image = lambda *a, **k: None
+    tv.io, tv.utils = io, ut
+    sys.modules["torchvision"], sys.modules["torchvision.io"], sys.modules["torchvision.utils"] = tv, io, ut
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+
+
+class _UNetOut(dict):
+    """my_diffusers returns {"sample": ...}; the MasaCtrl pipeline (diffusers 0.15 API) reads `.sample`."""
+    __getattr__ = dict.__getitem__
+
+
+def build_masactrl_editor(cfg, unet_sd, vae_sd, tokenizer, text_encoder, num_ddim_steps):
+    """The reference's MasaCtrlEditor (run_editing_masactrl.py:57-74) on CPU with seeded weights, skipping from_pretrained.
+    The fork's attention class is called CrossAttention; the MasaCtrl hook looks for the diffusers-0.15 name `Attention`
+    (masactrl_utils.py:130), so the modules get a renamed subclass (same code)."""
+    install()
+    _install_fake_vision()
+    import diffusers
+    import run_editing_masactrl as rem
+    from models.masactrl.diffuser_utils import MasaCtrlPipeline
+    import utils.utils as ru
+    rem.txt_draw = ru.txt_draw
+    ed = rem.MasaCtrlEditor.__new__(rem.MasaCtrlEditor)
+    ed.device = torch.device("cpu")
+    ed.method_list = ["directinversion+masactrl"]
+    ed.num_ddim_steps = num_ddim_steps
+    ed.scheduler = diffusers.DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                                           set_alpha_to_one=False)
+    unet = build_unet(cfg, unet_sd)
+    for m in unet.modules():
+        if m.__class__.__name__ == "CrossAttention":
+            m.__class__ = type("Attention", (m.__class__,), {})
+    fwd = unet.forward
+    unet.forward = lambda *a, **k: _UNetOut(fwd(*a, **k))
+    pipe = MasaCtrlPipeline.__new__(MasaCtrlPipeline)
+    pipe.unet, pipe.vae = unet, build_vae(cfg, vae_sd)
+    pipe.tokenizer, pipe.text_encoder, pipe.scheduler = tokenizer, text_encoder, ed.scheduler
+    pipe.device = torch.device("cpu")
+    ed.model = pipe
+    ed.scheduler.set_timesteps(num_ddim_steps)
+    return ed

@@ -62,6 +62,10 @@ def attention(sd, pre, x, context, heads, hook, place):
     scale = d ** -0.5
     sim = torch.einsum("bid,bjd->bij", q, k) * scale
     attn = sim.softmax(dim=-1)
+    if hook is not None and hasattr(hook, "qkv_editor"):
+        # MasaCtrl-style hook (masactrl_utils.py:85-127): the editor gets q, k, v as well and returns the merged-head output
+        out = hook.qkv_editor(q, k, v, sim, attn, is_cross, place, heads, scale)
+        return _lin(sd, pre + ".to_out.0", out)
     if hook is not None:
         attn = hook(attn, is_cross, place)
     out = torch.einsum("bij,bjd->bid", attn, v)

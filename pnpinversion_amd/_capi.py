@@ -32,6 +32,7 @@ class CtrlDesc(C.Structure):
         ("self_replace_lo", C.c_int), ("self_replace_hi", C.c_int), ("self_replace_max_tokens", C.c_int),
         ("lb_enabled", C.c_int), ("lb_start", C.c_int), ("lb_threshold", C.c_float),
         ("lb_alpha_host", C.POINTER(C.c_float)),
+        ("masa_start_step", C.c_int), ("masa_start_layer", C.c_int),
     ]
 
 

@@ -398,6 +398,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
                            bool use_ctrl, int cur_step, half_t* out, Stats sx = Stats(), Stats* so = nullptr) {
   const pnpi_model_config& g = c->cfg;
   const size_t mk = c->temp.mark();
+  const int block_index = c->tf_index++;    // transformer blocks in execution order (down 0.., mid, up ..15)
   const int C = t.C, N = H * W, M = B * N, hd = t.heads * t.Dp, X = g.cross_dim, T = g.ctx_len;
   const float scale = 1.0f / sqrtf((float)t.dh);
   CtrlDev& cd = c->cd;
@@ -423,7 +424,8 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     AttnP a; a.q = qk; a.ldq = 2 * hd; a.q_off = 0; a.k = qk; a.ldk = 2 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv;
     a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
-    a.rows = rep ? cd.rows_rep : cd.rows_id; a.nrows = B;
+    const bool masa = use_ctrl && cd.masa_any && cur_step >= cd.masa_start_step && block_index >= cd.masa_start_layer;
+    a.rows = rep ? cd.rows_rep : (masa ? cd.rows_masa : cd.rows_id); a.nrows = B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
     if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, N, N, t.Dp, launch_attn_flash(a, c->st));
   }
@@ -496,6 +498,7 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
   if (rows <= 0 || rows > c->max_rows) return fail(c, PNPI_EINVAL, "unet rows out of range (max_unet_rows)");
   if (t < 0 || t >= g.n_train_timesteps) return fail(c, PNPI_EINVAL, "timestep out of range");
   c->persist.reset(); c->temp.reset();
+  c->tf_index = 0;
   const int S = g.sample_size, n = g.n_blocks, C0 = g.block_out_channels[0], TE = 4 * C0, G = g.norm_groups;
   const int B = rows;
   const float eps = 1e-5f;
@@ -719,6 +722,23 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
   if (cds) {
     if (rows != nimg * 4) return fail(c, PNPI_EINVAL, "controllers need rows == 4 * nimg");
     for (int i = 0; i < nimg; ++i) if (cds[i].kind == 1) edit_img.push_back(i);
+  }
+  if (cds) {   // MasaCtrl images (kind 2): rows [unc_src, unc_tgt, cond_src, cond_tgt]; each target row reads its half's source K, V
+    std::vector<int> masa = id;
+    for (int i = 0; i < nimg; ++i) {
+      if (cds[i].kind != 2) continue;
+      if (cd.masa_any && (cd.masa_start_step != cds[i].masa_start_step || cd.masa_start_layer != cds[i].masa_start_layer))
+        return fail(c, PNPI_EINVAL, "all MasaCtrl controllers of one batch must share start_step / start_layer");
+      cd.masa_any = true; cd.masa_start_step = cds[i].masa_start_step; cd.masa_start_layer = cds[i].masa_start_layer;
+      for (int half = 0; half < 2; ++half) {
+        const int src = i * 4 + 2 * half, tgt = src + 1;
+        masa[tgt * 4 + 2] = src; masa[tgt * 4 + 3] = src;
+      }
+    }
+    if (cd.masa_any) {
+      cd.rows_masa = (int*)c->ctrl_arena.alloc(masa.size() * sizeof(int));
+      CKP(upload(c, cd.rows_masa, masa.data(), masa.size() * sizeof(int)));
+    }
   }
   cd.any_edit = !edit_img.empty();
   cd.npairs = (int)edit_img.size();

@@ -125,6 +125,9 @@ struct CtrlDev {
   int* rows_id = nullptr;         // [rows][4] identity
   int* rows_rep = nullptr;        // [rows][4] self-attention replacement
   int* rows_plain = nullptr;      // rows that take the plain cross-attention path
+  int* rows_masa = nullptr;       // [rows][4] MasaCtrl: target rows read K, V of the source row of their CFG half
+  bool masa_any = false;
+  int masa_start_step = 0, masa_start_layer = 0;
   int n_plain = 0;
   int* pairs = nullptr;           // [npairs][2]
   half_t* mmatT = nullptr;        // [npairs][96][96]
@@ -142,6 +145,7 @@ struct pnpi_ctx {
   std::string err;
   int max_rows, max_vae;
   bool dry;
+  int tf_index = 0;   // transformer block counter of the forward in flight (MasaCtrl start_layer)
   Bump warena, persist, temp, ctrl_arena;
   float* splitk_ws; size_t splitk_bytes;
   float* gn_partial;

@@ -47,6 +47,19 @@ class ControllerTables:
         return d
 
 
+class MasaCtrlTables:
+    """MutualSelfAttentionControl (models/masactrl/masactrl.py:14-72) -> pnpi_ctrl_desc kind 2."""
+
+    def __init__(self, start_step=4, start_layer=10):
+        self.start_step, self.start_layer = int(start_step), int(start_layer)
+
+    def desc(self):
+        d = _capi.CtrlDesc()
+        d.kind = 2
+        d.masa_start_step, d.masa_start_layer = self.start_step, self.start_layer
+        return d
+
+
 def _desc_array(ctrls):
     """list[ControllerTables | None] -> (ctypes array of pnpi_ctrl_desc, keep-alive)"""
     if ctrls is None:

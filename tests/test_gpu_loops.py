@@ -284,3 +284,41 @@ def test_unbuilt_reference_methods_say_so(small64):
             ed(m, img, "a", "b")
     with pytest.raises(NotImplementedError, match="No edit method named"):
         ed("directinversion+p2p_guidance_9_9", img, "a", "b")
+
+
+@pytest.mark.parametrize("method", ["directinversion+masactrl", "ddim+masactrl"])
+def test_masactrl_editor_against_reference_golden(method):
+    """run_editing_masactrl.py MasaCtrlEditor on the native pipeline vs the stage outputs of the reference's own MasaCtrlEditor
+    (tests/golden/e2e_masactrl.npz: SMALL64, 6 steps, mutual self-attention from step 2 in transformer blocks 10..15)."""
+    from pnpinversion_amd.masactrl.diffuser_utils import MasaCtrlPipeline
+    from run_editing_masactrl import MasaCtrlEditor
+    g = np.load(os.path.join(GOLD, "e2e_masactrl.npz"))
+    cfg, steps = SMALL64, int(g["steps"])
+    pipe = MasaCtrlPipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    ed = MasaCtrlEditor([method], "cuda", num_ddim_steps=steps, pipeline=pipe)
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    fn = ed.edit_image_directinversion_MasaCtrl if method.startswith("direct") else ed.edit_image_ddim_MasaCtrl
+    panel, st = fn(img, str(g["src"]), str(g["tgt"]), 7.5, step=int(g["start_step"]), layper=int(g["start_layer"]), return_stages=True)
+    assert panel.size == (2048, 512)
+    xs = torch.stack([x.cpu() for x in st["x_stars"]])
+    assert rel(xs, g[method + "/x_stars"]) < 4e-3 * steps ** 0.5, rel(xs, g[method + "/x_stars"])
+    if method + "/noise_loss" in g:
+        nl = torch.stack([x.cpu() for x in st["noise_loss_list"]])
+        assert rel(nl, g[method + "/noise_loss"]) < 2e-2, rel(nl, g[method + "/noise_loss"])
+    p = np.array(panel)
+    rec_small, edit_small = p[::4, 1024:1536:4], p[::4, 1536::4]
+    assert np.abs(rec_small.astype(np.int32) - g[method + "/recon_image_small"].astype(np.int32)).mean() < 3.0
+    assert np.abs(edit_small.astype(np.int32) - g[method + "/edited_image_small"].astype(np.int32)).mean() < 4.0
+    # the editor matters: the same call without mutual self-attention gives a different target image
+    from pnpinversion_amd.masactrl.masactrl_utils import AttentionBase, regiter_attention_editor_diffusers
+    regiter_attention_editor_diffusers(pipe, AttentionBase())
+    start = st["x_stars"][-1].expand(2, -1, -1, -1)
+    nl = st.get("noise_loss_list")
+    plain = pipe(["", str(g["tgt"])], latents=start, num_inference_steps=steps, guidance_scale=7.5, noise_loss_list=nl)
+    assert (plain[1] - st["images"][1]).abs().mean().item() > 1e-3
+    assert torch.equal(plain[0], st["images"][0])          # the source row never reads another row
+    with pytest.raises(NotImplementedError, match="No edit method named"):
+        ed("masactrl", img, "a", "b", 7.5)
+    pipe.engine.close()

@@ -116,8 +116,10 @@ def test_loops_and_controllers_match_reference(name):
     assert rel(out[0], x_stars[0][0]) < 1e-4
 
 
-VARIANTS = ["ddim+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5", "ablation_directinversion_04+p2p",
-            "ablation_directinversion_interval_2+p2p", "ablation_directinversion_add-target+p2p"]
+# four of the six golden variants run here (each turns a different knob; the CPU suite has to stay within minutes); all six
+# are checked against the HIP path in tests/test_gpu_loops.py
+VARIANTS = ["negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5", "ablation_directinversion_interval_2+p2p",
+            "ablation_directinversion_add-target+p2p"]
 
 
 @pytest.mark.parametrize("method", VARIANTS)
@@ -168,3 +170,30 @@ def test_loop_variants_match_reference(method):
         ref_nl = torch.from_numpy(g["noise_loss"])
     out = po.guidance_forward(unet_fn, xs[-1], ctx, [x for x in ref_nl], ctrl, ts, ac_, ac_[0], gs, offset_rows=rows)
     assert rel(out, ref_edit) < 5e-5, rel(out, ref_edit)
+
+
+def test_masactrl_matches_reference():
+    """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl") stage outputs (tests/golden/e2e_masactrl.npz: SMALL64,
+    6 steps, mutual self-attention from step 2 in blocks 10..15) vs the oracle's loops with the restated editor."""
+    from pnpinversion_amd.text import SyntheticTextEncoder, WordTokenizer
+    g = load("e2e_masactrl.npz")
+    m = "directinversion+masactrl"
+    cfg, steps = SMALL64, int(g["steps"])
+    usd = weights.unet_state_dict(cfg, 2)
+    tok, enc = WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7)
+    emb = lambda ps: enc(tok(ps, padding="max_length", max_length=77, return_tensors="pt").input_ids)[0]
+    ctx = torch.cat([emb(["", ""]), emb(["", str(g["tgt"])])])          # prompts = ["", prompt_tar]
+    x_stars = torch.from_numpy(g[m + "/x_stars"])
+    ac_, ts = po.alphas_cumprod(), po.make_timesteps(steps)
+
+    def unet_fn(lat, t, c, hook):
+        with torch.no_grad():
+            return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    lat = po.ddim_loop(unet_fn, x_stars[0], ctx[2:3], ts, ac_, ac_[0])      # inversion of the "" prompt (cheap: B = 1)
+    assert rel(torch.stack(lat), x_stars) < 2e-5
+    nl_ref = torch.from_numpy(g[m + "/noise_loss"])                         # (offset_calculate is pinned by the P2P tests)
+    editor = po.MasaCtrlEditor(int(g["start_step"]), int(g["start_layer"]))
+    out = po.guidance_forward(unet_fn, x_stars[-1], ctx, [x for x in nl_ref], editor, ts, ac_, ac_[0], 7.5)
+    assert rel(out, g[m + "/masactrl_latents"]) < 5e-5, rel(out, g[m + "/masactrl_latents"])
+    assert editor.cur_step == steps and editor.cur_att_layer == 0
