@@ -37,7 +37,7 @@ def setup_seed(seed=1234):
     random.seed(seed)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--rerun_exist_images", action="store_true")
     ap.add_argument("--data_path", type=str, default="data")
@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--edit_category_list", nargs="+", type=str, default=[str(i) for i in range(10)])
     ap.add_argument("--edit_method_list", nargs="+", type=str, default=["directinversion+p2p"])
     ap.add_argument("--batch_size", type=int, default=1, help="images per set of launches and GPU (not in the reference: it edits one by one)")
-    args = ap.parse_args()
+    ap.add_argument("--model_config", choices=("sd1", "small64"), default="sd1", help="small64: reduced-width test configuration")
+    ap.add_argument("--num_ddim_steps", type=int, default=50)
+    args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,14 +56,15 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from pnpinversion_amd import weights
-    from pnpinversion_amd.config import SD1
+    from pnpinversion_amd.config import SD1, SMALL64
     from pnpinversion_amd.pipeline import NativePipeline
-    pipe = NativePipeline(SD1, device="cuda:%d" % local_rank, max_unet_rows=12 * max(1, args.batch_size))
+    cfg = SD1 if args.model_config == "sd1" else SMALL64
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 * max(1, args.batch_size))
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(SD1, 0), weights.vae_state_dict(SD1, 0))   # no SD checkpoint offline
+        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0))   # no SD checkpoint offline
     if world > 1:
         broadcast_weights(pipe.engine, src=0)
-    editor = P2PEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=50, pipeline=pipe)
+    editor = P2PEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=args.num_ddim_steps, pipeline=pipe)
 
     with open(os.path.join(args.data_path, "mapping_file.json")) as f:
         instructions = json.load(f)

@@ -322,3 +322,33 @@ def test_masactrl_editor_against_reference_golden(method):
     with pytest.raises(NotImplementedError, match="No edit method named"):
         ed("masactrl", img, "a", "b", 7.5)
     pipe.engine.close()
+
+
+def test_sweep_driver_cli(tmp_path, capsys):
+    """run_editing_p2p.py end to end on a 3-image PIE-Bench-shaped data directory: output tree of the reference
+    (output/<method>/annotation_images/...), --batch_size grouping, skip-if-exists resume (run_editing_p2p.py:239-300)."""
+    import json
+    from PIL import Image
+    import run_editing_p2p as drv
+    data, out = tmp_path / "data", tmp_path / "output"
+    (data / "annotation_images" / "0_random").mkdir(parents=True)
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    mapping = {}
+    for i in range(3):
+        rel_path = "0_random/%03d.jpg" % i
+        Image.fromarray(np.roll(img, 17 * i, axis=1)).save(str(data / "annotation_images" / rel_path))
+        mapping["%012d" % i] = {"image_path": rel_path, "original_prompt": "a [cat] sitting on a wooden chair",
+                                "editing_prompt": "a [dog] sitting on a wooden chair", "editing_type_id": "0",
+                                "blended_word": "cat dog" if i != 1 else "", "mask": [0, 100, 5000, 300]}
+    (data / "mapping_file.json").write_text(json.dumps(mapping))
+    argv = ["--data_path", str(data), "--output_path", str(out), "--model_config", "small64", "--num_ddim_steps", "3",
+            "--batch_size", "2", "--edit_category_list", "0"]
+    drv.main(argv)
+    files = sorted((out / "directinversion+p2p" / "annotation_images" / "0_random").glob("*.jpg"))
+    assert [f.name for f in files] == ["000.jpg", "001.jpg", "002.jpg"]
+    assert Image.open(str(files[0])).size == (2048, 512)
+    first = capsys.readouterr().out
+    assert first.count("editing image") == 3 and "skip image" not in first
+    drv.main(argv)                                   # second pass: everything exists -> skipped, nothing edited
+    second = capsys.readouterr().out
+    assert second.count("skip image") == 3 and "editing image" not in second
