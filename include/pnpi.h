@@ -154,7 +154,12 @@ int pnpi_ddim_prev_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, 
  *   else noise_loss (nullable) [nimg][R][E] added to the first offset_rows rows. */
 int pnpi_cfg_ddim_prev(pnpi_ctx* ctx, const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems,
                        float guidance_scale, int t, int step_ratio, const float* noise_loss, int offset_rows,
-                       const float* target, float offset_scale, float* offset_out, float* x_out);
+                       const float* target, float offset_scale, float* offset_out, float* x_out,
+                       const float* prox_threshold /*[nimg] device, nullable*/, int prox /*0 none, 1 l0, 2 l1*/);
+/* threshold of the proximal-guidance step (proximal_guidance_forward.py:41,53): torch.quantile(|eps_c - eps_u|, q) with the
+ * default linear interpolation over the rows of each image; eps [nimg][2R][E] -> thr_out [nimg] (device) */
+int pnpi_prox_threshold(pnpi_ctx* ctx, const float* eps, int nimg, int rows_per_img, size_t row_elems, float quantile,
+                        float* thr_out);
 
 /* ---- level 2: loop boundary (whole phases device-resident, no host round trip per step) ------------------------- */
 /* DirectInversion.ddim_loop (inversion.py:308-319): latents_out [nsteps+1][nimg][4][h][w]; timesteps_host = scheduler.timesteps */
@@ -171,11 +176,14 @@ int pnpi_ddim_invert_cfg(pnpi_ctx* ctx, const float* z0, int nimg, const float* 
                          const float* ctx_cond, float guidance_scale, int nsteps, const int* timesteps_host,
                          float* latents_out);
 /* direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) incl. controller + LocalBlend:
- * latents_out [nimg][2][4][h][w].  ctrl_host: nullable or [nimg]. */
+ * latents_out [nimg][2][4][h][w].  ctrl_host: nullable or [nimg].
+ * prox 1 ('l0') / 2 ('l1'): the proximal-guidance step of proximal_guidance_forward.py:39-64 -- the CFG difference is
+ * soft-thresholded at quantile `quantile` of its magnitude over the image's two rows (torch.quantile, linear); a
+ * quantile <= 0 means the fixed threshold -quantile.  prox 0: plain CFG. */
 int pnpi_edit_loop(pnpi_ctx* ctx, const float* x_T /*[nimg][4][h][w]*/, int nimg, const float* context4,
                    const float* noise_loss /*[nsteps][nimg][2][...], nullable*/, int offset_rows,
                    const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* timesteps_host, float guidance_scale,
-                   float* latents_out);
+                   int prox, float quantile, float* latents_out);
 
 /* The denoising half of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) as ONE loop: offset_calculate
  * (inversion.py:375-391) and npass direct_inversion_p2p_guidance_forward passes (p2p_guidance_forward.py:135-173; the

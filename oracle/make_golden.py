@@ -14,6 +14,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
                        negative-prompt-inversion+p2p, a vary-guidance, a not_full, a skip_step and the add-target ablation):
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
   e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
+  e2e_proximal.npz     P2PEditor("negative-prompt-inversion+proximal-guidance") with the sweep script's arguments (l0) and l1
 """
 import json
 import os
@@ -223,6 +224,43 @@ def variants(steps=2):
     np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
 
 
+def proximal(steps=2):
+    """P2PEditor("negative-prompt-inversion+proximal-guidance") with the arguments run_editing_p2p.py:286-300 passes
+    (proximal="l0", quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400), and the 'l1' variant."""
+    ref_shim.install()
+    cfg = SMALL64
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, w0, w1 = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    import models.p2p_editor as pe
+    out = {"steps": np.int64(steps), "src": src, "tgt": tgt, "blend": np.array([w0, w1])}
+    for prox in ("l0", "l1"):
+        calls = []
+        saved = pe.proximal_guidance_forward
+
+        def spy(*a, **k):
+            r = saved(*a, **k)
+            calls.append(r[0].clone().numpy())
+            return r
+
+        pe.proximal_guidance_forward = spy
+        try:
+            with ref_shim.cuda_to_cpu(), torch.no_grad():
+                panel = ed("negative-prompt-inversion+proximal-guidance", image_path=img, prompt_src=src, prompt_tar=tgt,
+                           guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+                           eq_params={"words": (w1,), "values": (2,)}, proximal=prox, quantile=0.75, use_inversion_guidance=True,
+                           recon_lr=1, recon_t=400)
+        finally:
+            pe.proximal_guidance_forward = saved
+        assert len(calls) == 2
+        out[prox + "/reconstruct_latent"], out[prox + "/edited_latents"] = calls
+        out[prox + "/edited_image_small"] = np.array(panel)[::4, 3 * 512::4]
+        print("proximal", prox, {k: v.shape for k, v in out.items() if k.startswith(prox + "/")})
+    np.savez_compressed(os.path.join(OUT, "e2e_proximal.npz"), **out)
+
+
 def masactrl(steps=6, start_step=2, start_layer=10):
     """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -291,7 +329,7 @@ def masactrl(steps=6, start_step=2, start_layer=10):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl"]
+    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl", "proximal"]
     if "host" in which:
         host_tables()
     if "models" in which:
@@ -303,3 +341,5 @@ if __name__ == "__main__":
         variants()
     if "masactrl" in which:
         masactrl()
+    if "proximal" in which:
+        proximal()

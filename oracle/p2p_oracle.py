@@ -263,8 +263,10 @@ def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guid
 
 
 def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timesteps, ac, final, guidance_scale, offset_rows=1,
-                     collect=None):
-    """direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) + ..._diffusion_step (:103-116)."""
+                     collect=None, prox=None, quantile=0.7):
+    """direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) + ..._diffusion_step (:103-116).
+    prox 'l0' / 'l1': the proximal step of proximal_guidance_diffusion_step (proximal_guidance_forward.py:39-64) with no
+    reference image and no inversion guidance (what the reference's editors reach)."""
     n = len(timesteps)
     ratio = len(ac) // n
     nrow = context4.shape[0] // 2
@@ -273,7 +275,14 @@ def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timest
         t = int(timesteps[i])
         eps = unet_fn(torch.cat([lat] * 2), t, context4, controller)
         eu, ec = eps.chunk(2)
-        e = eu + guidance_scale * (ec - eu)
+        d = ec - eu
+        if prox is not None:
+            thr = d.abs().quantile(quantile) if quantile > 0 else -quantile
+            d = d - d.clamp(-thr, thr)
+            if prox == "l1":
+                d = torch.where(d > 0, d - thr, d)
+                d = torch.where(d < 0, d + thr, d)
+        e = eu + guidance_scale * d
         a_t, a_p = prev_alphas(ac, final, t, ratio)
         lat = ddim_move(lat, e, float(a_t), float(a_p))
         if noise_loss_list is not None:

@@ -74,11 +74,12 @@ SYMBOLS = {
     "pnpi_latent2image": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pnpi_ddim_next_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "pnpi_ddim_prev_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _f, _vp, _vp]),
+    "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _i]),
+    "pnpi_prox_threshold": (_i, [_vp, _vp, _i, _i, _sz, _f, _vp]),
     "pnpi_ddim_invert": (_i, [_vp, _vp, _i, _vp, _i, _ip, _vp]),
     "pnpi_ddim_invert_cfg": (_i, [_vp, _vp, _i, _vp, _vp, _f, _i, _ip, _vp]),
     "pnpi_offset_calculate": (_i, [_vp, _vp, _i, _vp, _i, _ip, _f, _fp, _vp]),
-    "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _vp]),
+    "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _i, _f, _vp]),
     "pnpi_direct_edit": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CtrlDesc), _i, _i, _ip, _f, _fp, _vp, _vp]),
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     "pnpi_op_gemm": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i]),

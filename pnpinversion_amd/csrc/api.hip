@@ -1169,9 +1169,19 @@ int pnpi_ddim_prev_step(pnpi_ctx* c, const float* eps, int t, int ratio, const f
 }
 int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, int rpi, size_t row_elems, float gs, int t, int ratio,
                        const float* noise_loss, int offset_rows, const float* target, float offset_scale, float* offset_out,
-                       float* x_out) {
+                       float* x_out, const float* prox_threshold, int prox) {
+  if (prox < 0 || prox > 2 || (prox && !prox_threshold)) return fail(c, PNPI_EINVAL, "prox must be 0, or 1 / 2 with a threshold");
   float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
-  CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_scale, offset_out, x_out, c->st));
+  CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_scale, offset_out, x_out, c->st,
+                          prox_threshold, prox));
+  return 0;
+}
+
+int pnpi_prox_threshold(pnpi_ctx* c, const float* eps, int nimg, int rpi, size_t row_elems, float quantile, float* thr_out) {
+  if (!c || !eps || !thr_out || nimg <= 0 || !(quantile > 0.f && quantile <= 1.f)) return PNPI_EINVAL;
+  int r = launch_quantile_abs_diff(eps, nimg, rpi, row_elems, quantile, thr_out, c->st);
+  if (r == -6) return fail(c, PNPI_ESHAPE, "proximal threshold: more than 32768 elements per image");
+  CK(r);
   return 0;
 }
 
@@ -1272,7 +1282,7 @@ int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const flo
 }
 
 int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
-                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, float* latents_out) {
+                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile, float* latents_out) {
   if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   const pnpi_model_config& g = c->cfg;
@@ -1282,15 +1292,18 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   if (ctrl_host) CKP(setup_ctrl(c, ctrl_host, nimg, rows));
   else CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
   const bool use_ctrl = ctrl_host != nullptr;
+  if (prox < 0 || prox > 2) return fail(c, PNPI_EINVAL, "prox must be 0 (none), 1 (l0) or 2 (l1)");
   float* lat = misc_f(c, (size_t)nimg * 2 * E);
   float* in = misc_f(c, (size_t)rows * E);
   float* eps = misc_f(c, (size_t)rows * E);
+  float* thr = misc_f(c, (size_t)nimg);
   std::vector<int> expand(nimg * 2), inmap(rows);
   for (int i = 0; i < nimg; ++i) { expand[2 * i] = i; expand[2 * i + 1] = i; for (int k = 0; k < 4; ++k) inmap[4 * i + k] = 2 * i + (k & 1); }
   int *d_expand, *d_inmap;
   CKP(upload_ints(c, expand, &d_expand));
   CKP(upload_ints(c, inmap, &d_inmap));
   CK(launch_gather_rows_f32(x_T, d_expand, nimg * 2, E, lat, c->st));
+  if (prox && !(quantile > 0.f)) CK(launch_fill_f32(thr, nimg, -quantile, c->st));   // negative quantile = fixed threshold (:43-44)
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
     CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
@@ -1298,7 +1311,8 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
     if (r) return r;
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
-    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st));
+    if (prox && quantile > 0.f) CK(launch_quantile_abs_diff(eps, nimg, 2, E, quantile, thr, c->st));
+    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st, prox ? thr : nullptr, prox));
     if (use_ctrl) CKP(apply_local_blend(c, lat, i));
   }
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));

@@ -683,7 +683,8 @@ static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 *
 static half_t* g_zero_page = nullptr;
 static constexpr size_t ZERO_PAGE_BYTES = 128 << 10;   // >= 2 * (longest K + one chunk): out-of-range rows walk it like real rows
 static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
-static int g_var128 = 2, g_var64 = 0, g_var256 = 0;   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
+static int g_var128 = 2, g_var64 = 0, g_var256 = 0;
+static long g_v128_bk64_tiles = 0;   // PNPI_V128_BK64_TILES: tile count from which the 128x128 kernel switches to 128-byte rows   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
 void igemm_set_dma(int on) { g_use_dma = on; }
 
 int igemm_init() {
@@ -691,6 +692,7 @@ int igemm_init() {
   if (const char* e = getenv("PNPI_IGEMM_V128")) g_var128 = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V64")) g_var64 = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V256")) g_var256 = atoi(e);
+  if (const char* e = getenv("PNPI_V128_BK64_TILES")) g_v128_bk64_tiles = atol(e);
   if (const char* e = getenv("PNPI_TILE_ORDER")) g_tile_order = atoi(e);
   if (!g_zero_page) {
     HIP_CHECK_RET(hipMalloc((void**)&g_zero_page, ZERO_PAGE_BYTES));
@@ -768,7 +770,11 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, split);
     if (dma) {
       int r;
-      switch (g_var128) {
+      int var = g_var128;
+      // 128-byte rows with 2 stages (64 KB, 2 blocks / CU) beat 64-byte rows with 3 stages (48 KB, 3 blocks / CU) once every CU
+      // holds two blocks that cover for each other's exposed loads; below that the deeper ring wins
+      if (g_v128_bk64_tiles > 0 && var == 2 && (long)grid.x * grid.y * grid.z >= g_v128_bk64_tiles) var = 0;
+      switch (var) {
         case 1: r = launch_dma<128, 128, 64, 3>(p, grid, st, g_zero_page); break;
         case 2: r = launch_dma<128, 128, 32, 3>(p, grid, st, g_zero_page); break;
         case 3: r = launch_dma<128, 128, 32, 4>(p, grid, st, g_zero_page); break;

@@ -107,6 +107,10 @@ int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to,
 // Classifier-free guidance + DDIM denoise step (+ direct-inversion offset). See include/pnpi.h pnpi_cfg_ddim_prev.
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale,
                          float a_t, float a_prev, const float* noise_loss, int offset_rows, const float* target,
-                         float offset_scale, float* offset_out, float* x_out, hipStream_t st);
+                         float offset_scale, float* offset_out, float* x_out, hipStream_t st, const float* prox_thr = nullptr,
+                         int prox_mode = 0);
+// threshold of the proximal-guidance step: quantile q of |eps_c - eps_u| over the rows of each image (torch.quantile, linear)
+int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_t row_elems, float q, float* thr_out, hipStream_t st);
+int launch_fill_f32(float* p, int n, float v, hipStream_t st);
 int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents,
                        int nimg, hipStream_t st);

@@ -45,7 +45,8 @@ int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to,
 __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float* __restrict__ x, int nimg, int R, size_t E, float g,
                                      float sa_f, float sb_f, float sa_t, float sb_t, const float* __restrict__ noise_loss,
                                      int offset_rows, const float* __restrict__ target, float oscale,
-                                     float* __restrict__ offset_out, float* __restrict__ x_out) {
+                                     float* __restrict__ offset_out, float* __restrict__ x_out, const float* __restrict__ prox_thr,
+                                     int prox_mode) {
   const size_t total = (size_t)nimg * R * E;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t e_idx = i % E;
@@ -54,7 +55,18 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
     int img = (int)(ir / R);
     float eu = eps[((size_t)img * 2 * R + r) * E + e_idx];
     float ec = eps[((size_t)img * 2 * R + R + r) * E + e_idx];
-    float e = __fadd_rn(eu, __fmul_rn(g, __fsub_rn(ec, eu)));
+    float d = __fsub_rn(ec, eu);
+    if (prox_mode) {
+      // proximal guidance (proximal_guidance_forward.py:39-62): score_delta -= clamp(score_delta, -thr, thr); 'l1' then shrinks
+      // the survivors by thr once more on each side
+      const float th = prox_thr[img];
+      d = __fsub_rn(d, fminf(fmaxf(d, -th), th));
+      if (prox_mode == 2) {
+        if (d > 0.f) d = __fsub_rn(d, th);
+        if (d < 0.f) d = __fadd_rn(d, th);
+      }
+    }
+    float e = __fadd_rn(eu, __fmul_rn(g, d));
     float prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
     float outv = prev;
     if (target) {
@@ -72,14 +84,70 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
 
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale, float a_t,
                          float a_prev, const float* noise_loss, int offset_rows, const float* target, float offset_scale,
-                         float* offset_out, float* x_out, hipStream_t st) {
+                         float* offset_out, float* x_out, hipStream_t st, const float* prox_thr, int prox_mode) {
   float sa_f = sqrtf(a_t), sb_f = sqrtf(1.0f - a_t), sa_t = sqrtf(a_prev), sb_t = sqrtf(1.0f - a_prev);
   size_t total = (size_t)nimg * rows_per_img * row_elems;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   cfg_ddim_prev_kernel<<<blocks, 256, 0, st>>>(eps, x, nimg, rows_per_img, row_elems, gscale, sa_f, sb_f, sa_t, sb_t, noise_loss,
-                                               offset_rows, target, offset_scale, offset_out, x_out);
+                                               offset_rows, target, offset_scale, offset_out, x_out, prox_thr, prox_mode);
+  return (int)hipGetLastError();
+}
+
+// torch.quantile(|eps_c - eps_u|, q) over all R rows of one image (proximal_guidance_forward.py:41,53: the threshold of the
+// proximal step), default 'linear' interpolation: sort, pos = q * (n - 1), lerp(x[floor], x[floor + 1], frac).  One block per
+// image; the n <= 32768 magnitudes are sorted in LDS (bitonic, padded with +inf to a power of two).
+__global__ void __launch_bounds__(1024) quantile_abs_diff_kernel(const float* __restrict__ eps, int R, size_t E, float q, int npow2,
+                                                                 float* __restrict__ thr_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int n = (int)(R * E);
+  const float* base = eps + (size_t)img * 2 * R * E;
+  for (int i = tid; i < npow2; i += blockDim.x)
+    s[i] = i < n ? fabsf(__fsub_rn(base[(size_t)R * E + i], base[i])) : INFINITY;
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const float a = s[i], b = s[l];
+          if ((a > b) == up) { s[i] = b; s[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    const float pos = __fmul_rn(q, (float)(n - 1));
+    const int lo = (int)floorf(pos);
+    const int hi = lo + 1 < n ? lo + 1 : n - 1;
+    const float w = __fsub_rn(pos, (float)lo);
+    const float a = s[lo], b = s[hi];
+    // torch.lerp: a + w * (b - a) for w < 0.5, b - (b - a) * (1 - w) otherwise
+    thr_out[img] = w < 0.5f ? __fadd_rn(a, __fmul_rn(w, __fsub_rn(b, a))) : __fsub_rn(b, __fmul_rn(__fsub_rn(b, a), __fsub_rn(1.f, w)));
+  }
+}
+
+int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_t row_elems, float q, float* thr_out, hipStream_t st) {
+  const size_t n = (size_t)rows_per_img * row_elems;
+  int npow2 = 1;
+  while ((size_t)npow2 < n) npow2 <<= 1;
+  if (npow2 > 32768) return -6;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)quantile_abs_diff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4); attr = true; }
+  quantile_abs_diff_kernel<<<nimg, 1024, (size_t)npow2 * sizeof(float), st>>>(eps, rows_per_img, row_elems, q, npow2, thr_out);
+  return (int)hipGetLastError();
+}
+
+__global__ void fill_f32_kernel(float* p, int n, float v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int launch_fill_f32(float* p, int n, float v, hipStream_t st) {
+  fill_f32_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, n, v);
   return (int)hipGetLastError();
 }
 

@@ -321,7 +321,7 @@ class NativeEngine:
         self._keep = (lat, ctx, ts, arr, flat, sc)
         return nl, out
 
-    def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1):
+    def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1, prox=None, quantile=0.7):
         xT, ctx = self._f32(x_T), self._f32(context4)
         nl = self._f32(noise_loss) if noise_loss is not None else None
         n = len(timesteps)
@@ -329,6 +329,8 @@ class NativeEngine:
         out = torch.empty(nimg, 2, *xT.shape[1:], device=self.device)
         ts, tsp = self._ts(timesteps)
         arr = _desc_array(ctrls)
-        self._call("pnpi_edit_loop", _p(xT), nimg, _p(ctx), _p(nl), int(offset_rows), arr, n, tsp, float(guidance_scale), _p(out))
+        mode = {None: 0, "l0": 1, "l1": 2}[prox]
+        self._call("pnpi_edit_loop", _p(xT), nimg, _p(ctx), _p(nl), int(offset_rows), arr, n, tsp, float(guidance_scale), mode,
+                   float(quantile), _p(out))
         self._keep = (xT, ctx, nl, ts, arr, ctrls)
         return out

@@ -1,7 +1,13 @@
-"""proximal_guidance_forward with the signature of models/p2p/proximal_guidance_forward.py:84-170.  With prox=None -- how
-`negative-prompt-inversion+p2p` calls it (p2p_editor.py:59-66) -- every proximal / reconstruction-guidance branch is inert
-(mask_edit stays None, the scheduler gets recon_lr = 0) and the loop is the plain P2P CFG loop.  The l0 / l1 proximal variants
-need a device quantile + dilate and are not built."""
+"""proximal_guidance_forward with the signature of models/p2p/proximal_guidance_forward.py:84-170.
+
+What the reference's editors can reach (p2p_editor.py:324-413, 550-638; run_editing_p2p.py:286-300 passes proximal="l0",
+quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400):
+  * the proximal step itself (:39-64): the CFG difference is soft-thresholded at a quantile of its magnitude -- built
+    (device quantile + shrink fused into the CFG / DDIM-step kernel);
+  * reconstruction guidance (image_enc given, :48-51, scheduler_dev.py:68-76): only with use_reconstruction_guidance=True, which
+    neither driver sets -- not built;
+  * inversion guidance (:73-75): the editors never pass inversion_guidance=True to this function, and with the default False the
+    condition `mask_edit is not None and inversion_guidance and (...) or (recon_t < 0 and ...)` is False for recon_t > 0 -- inert."""
 import torch
 
 from .p2p_guidance_forward import p2p_guidance_forward
@@ -11,8 +17,13 @@ from .p2p_guidance_forward import p2p_guidance_forward
 def proximal_guidance_forward(model, prompt, controller, guidance_scale=7.5, generator=None, latent=None, uncond_embeddings=None,
                               edit_stage=True, prox=None, quantile=0.7, image_enc=None, recon_lr=0.1, recon_t=400,
                               inversion_guidance=False, x_stars=None, dilate_mask=None, num_inference_steps=None):
-    if edit_stage and prox is not None:
-        raise NotImplementedError("proximal guidance (prox = %r) is not built (SURVEY 8f rank 3)" % (prox,))
+    if edit_stage and prox is not None and prox not in ("l0", "l1"):
+        raise NotImplementedError
+    if edit_stage and prox is not None and image_enc is not None and recon_lr > 0:
+        raise NotImplementedError("reconstruction guidance (image_enc) is not built (SURVEY 8f rank 3)")
+    if inversion_guidance or recon_t < 0:
+        raise NotImplementedError("inversion guidance / negative recon_t are not built (no reference editor passes them)")
     steps = num_inference_steps if num_inference_steps is not None else model.scheduler.num_inference_steps
     return p2p_guidance_forward(model=model, prompt=prompt, controller=controller, num_inference_steps=steps,
-                                guidance_scale=guidance_scale, generator=generator, latent=latent, uncond_embeddings=uncond_embeddings)
+                                guidance_scale=guidance_scale, generator=generator, latent=latent, uncond_embeddings=uncond_embeddings,
+                                prox=prox if edit_stage else None, quantile=quantile)

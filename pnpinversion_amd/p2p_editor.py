@@ -76,7 +76,10 @@ class P2PEditor:
                            "ablation_null-latent-inversion+p2p"):
             raise NotImplementedError(f"{edit_method}: optimises through the UNet (backward pass); not built (SURVEY 8f rank 4)")
         if edit_method == "negative-prompt-inversion+proximal-guidance":
-            raise NotImplementedError(f"{edit_method}: proximal guidance (quantile select + dilate) is not built (SURVEY 8f rank 3)")
+            return self.edit_image_negative_prompt_inversion(image_path, prompt_src, prompt_tar, proximal=proximal, quantile=quantile,
+                                                             use_reconstruction_guidance=use_reconstruction_guidance,
+                                                             recon_t=recon_t, recon_lr=recon_lr,
+                                                             use_inversion_guidance=use_inversion_guidance, dilate_mask=dilate_mask, **kw)
         raise NotImplementedError(f"No edit method named {edit_method}")
 
     def edit_image_directinversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
@@ -186,14 +189,20 @@ class P2PEditor:
                                              cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=None, eq_params=None,
                                              is_replace_controller=False, use_inversion_guidance=False, dilate_mask=1,
                                              return_stages=False):
-        """models/p2p_editor.py:324-413 with proximal=None (the +p2p method): the source prompt's embedding replaces "" """
-        if proximal is not None:
-            raise NotImplementedError("proximal guidance is not built (SURVEY 8f rank 3)")
+        """models/p2p_editor.py:324-413: the source prompt's embedding replaces "" in the unconditional rows; with proximal
+        "l0" / "l1" the edit pass soft-thresholds the CFG difference (proximal_guidance_forward.py:39-64)."""
+        if use_reconstruction_guidance:
+            raise NotImplementedError("reconstruction guidance is not built (SURVEY 8f rank 3)")
         image_gt, side = self._load(image_path)
         self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
         inv = NegativePromptInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
         _, _, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, npi_interp=npi_interp)
-        fwd = lambda **k: proximal_guidance_forward(edit_stage=True, prox=None, num_inference_steps=self.num_ddim_steps, **k)   # noqa: E731
+        def fwd(**k):   # reconstruction: edit_stage=False (no proximal step); edit: the method's prox / quantile
+            edit = len(k["prompt"]) == 2
+            return proximal_guidance_forward(edit_stage=edit, prox=proximal if edit else None, quantile=quantile,
+                                             recon_lr=recon_lr if use_inversion_guidance else 0,
+                                             recon_t=recon_t if use_inversion_guidance else 1000, dilate_mask=dilate_mask,
+                                             num_inference_steps=self.num_ddim_steps, **k)
         return self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                                self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
 

@@ -326,13 +326,13 @@ def test_step_kernels_bit_exact(ctx):
         off = torch.empty(2, 4, 16, 16, device=DEV)
         xo = torch.empty(2, 4, 16, 16, device=DEV)
         td = target.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), 1.0, ptr(off), ptr(xo))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), 1.0, ptr(off), ptr(xo), None, 0)
         assert torch.equal(off.cpu(), loss) and torch.equal(xo.cpu(), cur), t
         # guidance step with noise_loss on the first row only (p2p_guidance_forward.py:110-114)
         nl = torch.randn(2, 4, 16, 16, generator=g)
         ref2 = torch.cat((prev[:1] + nl[:1], prev[1:]))
         nld = nl.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, 1.0, None, ptr(xo))
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, 1.0, None, ptr(xo), None, 0)
         assert torch.equal(xo.cpu(), ref2), t
         # DDIMSchedulerDev.step == prev_step
         ctx.call("pnpi_ddim_prev_step", ptr(ed), t, 20, ptr(xd), x.numel(), ptr(out))
@@ -357,3 +357,33 @@ def test_local_blend(ctx):
     x_t = lat[0]
     ref = x_t[:1] + m.float() * (x_t - x_t[:1])
     assert torch.equal(d_lat.cpu()[0], ref)
+
+
+@pytest.mark.parametrize("prox", ["l0", "l1"])
+def test_proximal_step_bit_exact(ctx, prox):
+    """pnpi_prox_threshold = torch.quantile(|eps_c - eps_u|, q) (sort + linear interpolation) and the soft-threshold inside the
+    CFG / DDIM-step kernel (proximal_guidance_forward.py:39-64), bit for bit against the oracle formulas on the same eps."""
+    from oracle import p2p_oracle as po
+    g = torch.Generator().manual_seed(11)
+    eps = torch.randn(4, 4, 64, 64, generator=g)                    # [unc_src, unc_tgt, cond_src, cond_tgt]
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    ac, t, ratio = po.alphas_cumprod(), 481, 20
+    ctx.call("pnpi_set_scheduler", (C.c_float * 1000)(*ac.tolist()), 1000, float(ac[0]))
+    ed, xd = eps.cuda(), x.cuda()
+    thr_d = torch.empty(1, device="cuda")
+    xo = torch.empty_like(xd)
+    for q in (0.75, 0.7, 0.31):
+        ctx.call("pnpi_prox_threshold", ptr(ed), 1, 2, x[0].numel(), q, ptr(thr_d))
+        d = eps[2:] - eps[:2]
+        thr = d.abs().quantile(q)
+        assert torch.equal(thr_d.cpu()[0], thr), (q, thr_d.item(), thr.item())
+        ctx.call("pnpi_cfg_ddim_prev", ptr(ed), ptr(xd), 1, 2, x[0].numel(), 7.5, t, ratio, None, 0, None, 1.0, None, ptr(xo),
+                 ptr(thr_d), 1 if prox == "l0" else 2)
+        sd = d - d.clamp(-thr, thr)
+        if prox == "l1":
+            sd = torch.where(sd > 0, sd - thr, sd)
+            sd = torch.where(sd < 0, sd + thr, sd)
+        e = eps[:2] + 7.5 * sd
+        a_t, a_p = po.prev_alphas(ac, ac[0], t, ratio)
+        want = po.ddim_move(x, e, float(a_t), float(a_p))
+        assert torch.equal(xo.cpu(), want), (xo.cpu() - want).abs().max()

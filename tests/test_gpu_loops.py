@@ -279,7 +279,7 @@ def test_editor_method_variants_against_reference_golden(small64, method, lockst
 def test_unbuilt_reference_methods_say_so(small64):
     ed = P2PEditor(["x"], "cuda", num_ddim_steps=2, pipeline=small64)
     img = np.zeros((64, 64, 3), np.uint8)
-    for m in ("null-text-inversion+p2p", "negative-prompt-inversion+proximal-guidance", "ablation_null-latent-inversion+p2p"):
+    for m in ("null-text-inversion+p2p", "null-text-inversion+proximal-guidance", "ablation_null-latent-inversion+p2p"):
         with pytest.raises(NotImplementedError, match="not built"):
             ed(m, img, "a", "b")
     with pytest.raises(NotImplementedError, match="No edit method named"):
@@ -352,3 +352,29 @@ def test_sweep_driver_cli(tmp_path, capsys):
     drv.main(argv)                                   # second pass: everything exists -> skipped, nothing edited
     second = capsys.readouterr().out
     assert second.count("skip image") == 3 and "editing image" not in second
+
+
+@pytest.mark.parametrize("prox", ["l0", "l1"])
+def test_proximal_guidance_against_reference_golden(small64, prox):
+    """"negative-prompt-inversion+proximal-guidance" with the arguments run_editing_p2p.py passes to every method."""
+    v = np.load(os.path.join(GOLD, "e2e_proximal.npz"))
+    steps = int(v["steps"])
+    ed = P2PEditor(["negative-prompt-inversion+proximal-guidance"], "cuda", num_ddim_steps=steps, pipeline=small64)
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    w0, w1 = [str(x) for x in v["blend"]]
+    kw = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+              eq_params={"words": (w1,), "values": (2,)})
+    panel = ed("negative-prompt-inversion+proximal-guidance", img, str(v["src"]), str(v["tgt"]), proximal=prox, quantile=0.75,
+               use_inversion_guidance=True, recon_lr=1, recon_t=400, **kw)
+    small = np.array(panel)[::4, 1536::4]
+    assert np.abs(small.astype(np.int32) - v[prox + "/edited_image_small"].astype(np.int32)).mean() < 4.0
+    _, st = ed.edit_image_negative_prompt_inversion(img, str(v["src"]), str(v["tgt"]), proximal=prox, quantile=0.75,
+                                                    use_inversion_guidance=True, recon_lr=1, recon_t=400, return_stages=True, **kw)
+    # the shrink is a hard decision per element (|d| <= thr -> 0): elements within fp16 noise of the threshold fall on the other
+    # side than in the fp32 reference and move by up to guidance_scale * thr -- counted like LocalBlend mask flips (<= 2 % of pixels)
+    r, frac = masked_rel(st["latents"], torch.from_numpy(v[prox + "/edited_latents"]), tol_frac=0.02)
+    assert frac <= 0.02 and r < 2.5e-2, (prox, r, frac)
+    assert rel(st["reconstruct_latent"].cpu()[:1], v[prox + "/reconstruct_latent"][:1]) < 2.5e-2
+    other = "l1" if prox == "l0" else "l0"
+    assert rel(st["latents"], v[other + "/edited_latents"]) > 3 * r                        # and not the other variant

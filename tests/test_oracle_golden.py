@@ -197,3 +197,24 @@ def test_masactrl_matches_reference():
     out = po.guidance_forward(unet_fn, x_stars[-1], ctx, [x for x in nl_ref], editor, ts, ac_, ac_[0], 7.5)
     assert rel(out, g[m + "/masactrl_latents"]) < 5e-5, rel(out, g[m + "/masactrl_latents"])
     assert editor.cur_step == steps and editor.cur_att_layer == 0
+
+
+def test_proximal_guidance_matches_reference():
+    """P2PEditor("negative-prompt-inversion+proximal-guidance") as run_editing_p2p.py calls it (proximal="l0", quantile=0.75,
+    use_inversion_guidance=True, recon_lr=1, recon_t=400): the oracle's edit loop with the proximal step."""
+    g, v = load("e2e_refine.npz"), load("e2e_proximal.npz")
+    cfg, steps = SMALL64, int(v["steps"])
+    usd = weights.unet_state_dict(cfg, 2)
+    ctx = torch.from_numpy(g["context"]).float()
+    c4 = torch.cat([ctx[2:3], ctx[2:3], ctx[2:]])                   # negative-prompt inversion: cond_src replaces ""
+    x_T = torch.from_numpy(g["x_stars"])[-1]
+    ac_, ts = po.alphas_cumprod(), po.make_timesteps(steps)
+
+    def unet_fn(lat, t, c, hook):
+        with torch.no_grad():
+            return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    ctrl = po.EditController(32, _tables_from_product(g, steps))
+    out = po.guidance_forward(unet_fn, x_T, c4, None, ctrl, ts, ac_, ac_[0], 7.5, prox="l0", quantile=0.75)
+    assert rel(out, v["l0/edited_latents"]) < 5e-5, rel(out, v["l0/edited_latents"])
+    assert rel(torch.from_numpy(v["l1/edited_latents"]), v["l0/edited_latents"]) > 1e-3      # the two variants differ
