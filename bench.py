@@ -115,9 +115,10 @@ def main():
     from pnpinversion_amd import weights
 
     cfg = SD1
-    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=max(12 * max(1, args.batch_images), 12) if args.schedule == "lockstep" else 4, max_vae_images=2)
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=max(12 * max(1, args.batch_images), 12) if args.schedule == "lockstep" else 4, max_vae_images=2,
+                          text_encoder="native")        # prompts are embedded by the device CLIP text transformer (A1)
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0))
+        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0), clip_sd=weights.clip_state_dict(cfg, 0))
     if world > 1:
         broadcast_weights(pipe.engine, src=0)       # the one collective: RCCL broadcast of the packed arena over xGMI
     editor = P2PEditor(["directinversion+p2p"], "cuda:%d" % local_rank, num_ddim_steps=args.ddim_steps, pipeline=pipe)

@@ -56,12 +56,18 @@ typedef struct {
   int vae_block_out_channels[4];   /* 128, 256, 512, 512 */
   int vae_layers_per_block;        /* 2 */
   int vae_norm_groups;             /* 32 */
+  /* CLIP text encoder (transformers CLIPTextModel: hidden = cross_dim, positions = ctx_len); clip_layers = 0: not built */
+  int clip_layers;                 /* 12 */
+  int clip_heads;                  /* 12 */
+  int clip_intermediate;           /* 3072 */
+  int clip_vocab;                  /* 49408 */
 } pnpi_model_config;
 
 void pnpi_config_sd1(pnpi_model_config* cfg);
 
 typedef struct {
-  const char* name;   /* diffusers state-dict key prefixed with "unet." or "vae." */
+  const char* name;   /* diffusers state-dict key prefixed with "unet." or "vae."; transformers CLIPTextModel key (with or
+                         without its "text_model." prefix) prefixed with "clip." */
   const void* data;   /* device pointer, contiguous, PyTorch layout ([out,in,kh,kw] / [out,in] / [n]) */
   int dtype;          /* 0 = fp32, 1 = fp16 */
   int ndim;
@@ -160,6 +166,11 @@ int pnpi_cfg_ddim_prev(pnpi_ctx* ctx, const float* eps, const float* x, int nimg
  * default linear interpolation over the rows of each image; eps [nimg][2R][E] -> thr_out [nimg] (device) */
 int pnpi_prox_threshold(pnpi_ctx* ctx, const float* eps, int nimg, int rows_per_img, size_t row_elems, float quantile,
                         float* thr_out);
+
+/* model.text_encoder(input_ids)[0] (inversion.py:290-306, p2p_guidance_forward.py:151-164): transformers CLIPTextModel
+ * last_hidden_state.  ids: device int32 [n][ctx_len]; out: fp32 [n][ctx_len][cross_dim].  Needs the "clip." weights; the UNet /
+ * VAE entry points do not. */
+int pnpi_text_encode(pnpi_ctx* ctx, const int32_t* input_ids, int n, float* hidden_out);
 
 /* ---- level 2: loop boundary (whole phases device-resident, no host round trip per step) ------------------------- */
 /* DirectInversion.ddim_loop (inversion.py:308-319): latents_out [nsteps+1][nimg][4][h][w]; timesteps_host = scheduler.timesteps */

@@ -15,6 +15,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
   e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
   e2e_proximal.npz     P2PEditor("negative-prompt-inversion+proximal-guidance") with the sweep script's arguments (l0) and l1
+  clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
 """
 import json
 import os
@@ -224,6 +225,29 @@ def variants(steps=2):
     np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
 
 
+def clip_text():
+    """transformers CLIPTextModel (the class the reference's pipeline instantiates as model.text_encoder) with the seeded weights
+    of weights.clip_state_dict: last_hidden_state for two prompts, reduced (TINY16's) and SD-1.x (ViT-L/14 text tower) sizes."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    tok = WordTokenizer()
+    ids = tok([PROMPT_PAIRS[0][0], PROMPT_PAIRS[2][1]], padding="max_length", max_length=77, return_tensors="pt").input_ids
+    for name, cfg, seed in (("tiny", TINY16, 4), ("sd1", SD1, 0)):
+        hc = CLIPTextConfig(vocab_size=cfg.clip_vocab, hidden_size=cfg.cross_dim, intermediate_size=cfg.clip_intermediate,
+                            num_hidden_layers=cfg.clip_layers, num_attention_heads=cfg.clip_heads,
+                            max_position_embeddings=cfg.ctx_len, hidden_act="quick_gelu")
+        m = CLIPTextModel(hc).eval()
+        sd = weights.clip_state_dict(cfg, seed)
+        own = m.state_dict()
+        pre = "text_model." if any(k.startswith("text_model.") for k in own) else ""
+        missing, unexpected = m.load_state_dict({pre + k: v for k, v in sd.items()}, strict=False)
+        assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+        with torch.no_grad():
+            out = m(ids)[0]
+        np.savez_compressed(os.path.join(OUT, "clip_%s.npz" % name), input_ids=ids.numpy().astype(np.int32), hidden=out.numpy(),
+                            seed=np.int64(seed))
+        print("clip", name, tuple(out.shape), float(out.std()))
+
+
 def proximal(steps=2):
     """P2PEditor("negative-prompt-inversion+proximal-guidance") with the arguments run_editing_p2p.py:286-300 passes
     (proximal="l0", quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400), and the 'l1' variant."""
@@ -329,7 +353,7 @@ def masactrl(steps=6, start_step=2, start_layer=10):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl", "proximal"]
+    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl", "proximal", "clip"]
     if "host" in which:
         host_tables()
     if "models" in which:
@@ -343,3 +367,5 @@ if __name__ == "__main__":
         masactrl()
     if "proximal" in which:
         proximal()
+    if "clip" in which:
+        clip_text()

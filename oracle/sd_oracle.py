@@ -186,3 +186,32 @@ def vae_decode(sd, cfg, z):
 
 def cast_sd(sd, dtype):
     return {k: v.to(dtype) for k, v in sd.items()}
+
+
+# ------------------------------------------------------------------------------------------------- CLIP text encoder
+def clip_text_forward(sd, cfg, input_ids):
+    """transformers CLIPTextModel(input_ids)[0] = last_hidden_state -- what `model.text_encoder(ids)[0]` is in the reference
+    (models/p2p/inversion.py:290-306, p2p_guidance_forward.py:151-164).  transformers is a third-party dependency of the reference
+    (environment/p2p_requirements.txt:2, unpinned; absent from /root/reference); this restates its published CLIPTextTransformer:
+    token + position embeddings; L pre-LayerNorm blocks [causal multi-head self-attention, quick_gelu MLP]; final LayerNorm.
+    Pinned against the installed transformers (5.15) in tests/golden/clip_*.npz.  sd: CLIPTextModel state dict, keys without the
+    older "text_model." prefix."""
+    F = torch.nn.functional
+    H, heads = cfg.cross_dim, cfg.clip_heads
+    d = H // heads
+    ids = torch.as_tensor(input_ids).long()
+    B, T = ids.shape
+    x = sd["embeddings.token_embedding.weight"].float()[ids] + sd["embeddings.position_embedding.weight"].float()[None, :T]
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    for l in range(cfg.clip_layers):
+        p = "encoder.layers.%d." % l
+        ln = lambda n, t: F.layer_norm(t, (H,), sd[p + n + ".weight"].float(), sd[p + n + ".bias"].float(), 1e-5)
+        lin = lambda n, t: F.linear(t, sd[p + n + ".weight"].float(), sd[p + n + ".bias"].float())
+        h = ln("layer_norm1", x)
+        q, k, v = (lin("self_attn." + n, h).reshape(B, T, heads, d).transpose(1, 2) for n in ("q_proj", "k_proj", "v_proj"))
+        att = (q @ k.transpose(-1, -2)) * d ** -0.5 + mask
+        o = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H)
+        x = x + lin("self_attn.out_proj", o)
+        h = lin("mlp.fc1", ln("layer_norm2", x))
+        x = x + lin("mlp.fc2", h * torch.sigmoid(1.702 * h))
+    return F.layer_norm(x, (H,), sd["final_layer_norm.weight"].float(), sd["final_layer_norm.bias"].float(), 1e-5)

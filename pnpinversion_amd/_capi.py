@@ -17,6 +17,7 @@ class ModelConfig(C.Structure):
         ("sample_size", C.c_int), ("norm_groups", C.c_int), ("n_train_timesteps", C.c_int),
         ("vae_in_channels", C.c_int), ("vae_latent_channels", C.c_int), ("vae_n_blocks", C.c_int),
         ("vae_block_out_channels", C.c_int * 4), ("vae_layers_per_block", C.c_int), ("vae_norm_groups", C.c_int),
+        ("clip_layers", C.c_int), ("clip_heads", C.c_int), ("clip_intermediate", C.c_int), ("clip_vocab", C.c_int),
     ]
 
 
@@ -76,6 +77,7 @@ SYMBOLS = {
     "pnpi_ddim_prev_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _i]),
     "pnpi_prox_threshold": (_i, [_vp, _vp, _i, _i, _sz, _f, _vp]),
+    "pnpi_text_encode": (_i, [_vp, _vp, _i, _vp]),
     "pnpi_ddim_invert": (_i, [_vp, _vp, _i, _vp, _i, _ip, _vp]),
     "pnpi_ddim_invert_cfg": (_i, [_vp, _vp, _i, _vp, _vp, _f, _i, _ip, _vp]),
     "pnpi_offset_calculate": (_i, [_vp, _vp, _i, _vp, _i, _ip, _f, _fp, _vp]),

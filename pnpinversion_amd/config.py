@@ -25,6 +25,11 @@ class ModelConfig:
     vae_block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
     vae_layers_per_block: int = 2
     vae_norm_groups: int = 32
+    # CLIP text encoder (transformers CLIPTextModel of SD-1.x: ViT-L/14 text tower); hidden = cross_dim, positions = ctx_len
+    clip_layers: int = 12
+    clip_heads: int = 12
+    clip_intermediate: int = 3072
+    clip_vocab: int = 49408
 
     @property
     def n_blocks(self):
@@ -48,6 +53,8 @@ class ModelConfig:
         for i in range(c.vae_n_blocks):
             c.vae_block_out_channels[i] = self.vae_block_out_channels[i]
         c.vae_layers_per_block, c.vae_norm_groups = self.vae_layers_per_block, self.vae_norm_groups
+        c.clip_layers, c.clip_heads = self.clip_layers, self.clip_heads
+        c.clip_intermediate, c.clip_vocab = self.clip_intermediate, self.clip_vocab
         return c
 
 
@@ -56,7 +63,7 @@ SD1 = ModelConfig()
 # Reduced-width configurations used by the parity tests (same graph, same code paths, CPU-oracle friendly).
 # (layers_per_block stays 2: the 0.3.0 fork the oracle is pinned against mis-sizes its downsampler for 1-layer blocks)
 TINY16 = ModelConfig(block_out_channels=(32, 64, 64, 64), cross_dim=64, sample_size=16, layers_per_block=2,
-                     vae_block_out_channels=(32, 32, 64, 64), vae_layers_per_block=2)
+                     vae_block_out_channels=(32, 32, 64, 64), vae_layers_per_block=2, clip_layers=2, clip_heads=2, clip_intermediate=256)
 # 64x64 latents (needed by LocalBlend's hard-coded 16x16 maps) with narrow channels
 SMALL64 = ModelConfig(block_out_channels=(32, 64, 128, 128), cross_dim=64, sample_size=64, layers_per_block=2,
-                      vae_block_out_channels=(32, 32, 64, 64), vae_layers_per_block=2)
+                      vae_block_out_channels=(32, 32, 64, 64), vae_layers_per_block=2, clip_layers=2, clip_heads=2, clip_intermediate=256)

@@ -259,6 +259,37 @@ static void build_model(pnpi_ctx* c) {
   }
   v.d_norm_out = make_norm(c, "vae.decoder.conv_norm_out", vb[0]);
   v.d_conv_out = make_conv(c, "vae.decoder.conv_out", vb[0], g.vae_in_channels, 3);
+
+  // ---- CLIP text encoder (transformers CLIPTextModel; keys without the optional "text_model." prefix)
+  ClipW& t = c->clip;
+  t = ClipW();
+  if (g.clip_layers > 0) {
+    t.H = g.cross_dim; t.heads = g.clip_heads; t.I = g.clip_intermediate; t.vocab = g.clip_vocab; t.T = g.ctx_len;
+    const int H = t.H;
+    t.tok = walloc_h(c, (size_t)t.vocab * H);
+    t.pos = walloc_h(c, (size_t)t.T * H);
+    reg_mat(c, "clip.embeddings.token_embedding.weight", t.tok, t.vocab, H, 1, H, H);
+    reg_mat(c, "clip.embeddings.position_embedding.weight", t.pos, t.T, H, 1, H, H);
+    for (int l = 0; l < g.clip_layers; ++l) {
+      const std::string pre = "clip.encoder.layers." + std::to_string(l);
+      ClipLayerW L;
+      L.ln1 = make_norm(c, pre + ".layer_norm1", H);
+      L.ln2 = make_norm(c, pre + ".layer_norm2", H);
+      L.w_qkv = walloc_h(c, (size_t)3 * H * H);
+      L.b_qkv = walloc_f(c, 3 * H);
+      reg_mat(c, pre + ".self_attn.q_proj.weight", L.w_qkv, H, H, 1, H, H, 0);
+      reg_mat(c, pre + ".self_attn.k_proj.weight", L.w_qkv, H, H, 1, H, H, H);
+      reg_mat(c, pre + ".self_attn.v_proj.weight", L.w_qkv, H, H, 1, H, H, 2 * H);
+      reg_vec(c, pre + ".self_attn.q_proj.bias", L.b_qkv, H);
+      reg_vec(c, pre + ".self_attn.k_proj.bias", L.b_qkv + H, H);
+      reg_vec(c, pre + ".self_attn.v_proj.bias", L.b_qkv + 2 * H, H);
+      L.out = make_lin(c, pre + ".self_attn.out_proj", H, H);
+      L.fc1 = make_lin(c, pre + ".mlp.fc1", H, t.I);
+      L.fc2 = make_lin(c, pre + ".mlp.fc2", t.I, H);
+      t.layers.push_back(L);
+    }
+    t.final_ln = make_norm(c, "clip.final_layer_norm", H);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- profiling
@@ -837,6 +868,7 @@ void pnpi_config_sd1(pnpi_model_config* g) {
   g->layers_per_block = 2; g->heads = 8; g->cross_dim = 768; g->ctx_len = 77; g->sample_size = 64; g->norm_groups = 32;
   g->n_train_timesteps = 1000; g->vae_in_channels = 3; g->vae_latent_channels = 4; g->vae_n_blocks = 4;
   g->vae_layers_per_block = 2; g->vae_norm_groups = 32;
+  g->clip_layers = 12; g->clip_heads = 12; g->clip_intermediate = 3072; g->clip_vocab = 49408;   /* CLIP ViT-L/14 text model */
 }
 
 const char* pnpi_last_error(const pnpi_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
@@ -856,8 +888,17 @@ static int validate_config(pnpi_ctx* c) {
     return fail(c, PNPI_ESHAPE, "cross_dim/ctx_len/in_channels unsupported");
   if (g.sample_size % (1 << (g.n_blocks - 1))) return fail(c, PNPI_ESHAPE, "sample_size must divide by 2^(n_blocks-1)");
   if (g.block_out_channels[0] % 2) return fail(c, PNPI_ESHAPE, "C0 must be even");
+  if (g.clip_layers < 0 || g.clip_layers > 48) return fail(c, PNPI_ESHAPE, "clip_layers out of range");
+  if (g.clip_layers > 0) {
+    if (g.clip_heads <= 0 || g.cross_dim % g.clip_heads) return fail(c, PNPI_ESHAPE, "cross_dim must divide by clip_heads");
+    const int dh = g.cross_dim / g.clip_heads;
+    if (dh % 32 || dh > 160) return fail(c, PNPI_ESHAPE, "CLIP head dim must be a multiple of 32 and <= 160");
+    if (g.clip_intermediate <= 0 || g.clip_intermediate % 8 || g.clip_vocab <= 0) return fail(c, PNPI_ESHAPE, "clip_intermediate / clip_vocab invalid");
+  }
   return 0;
 }
+
+static int clip_fwd(pnpi_ctx* c, const int* ids, int n, float* out);
 
 int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images) {
   if (!out || !cfg) return PNPI_EINVAL;
@@ -910,6 +951,13 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
     CKH(hipMalloc((void**)&c->ctrl_arena.base, cap));
     c->ctrl_arena.cap = cap;
   }
+  {
+    c->rows_ident_n = max_unet_rows > 8 ? max_unet_rows : 8;
+    std::vector<int> idt((size_t)c->rows_ident_n * 4);
+    for (int r = 0; r < c->rows_ident_n; ++r) idt[4 * r] = idt[4 * r + 1] = idt[4 * r + 2] = idt[4 * r + 3] = r;
+    CKH(hipMalloc((void**)&c->rows_ident, idt.size() * sizeof(int)));
+    CKH(hipMemcpy(c->rows_ident, idt.data(), idt.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   // dry runs to size the activation workspaces
   c->dry = true;
   c->persist = Bump(); c->temp = Bump();
@@ -918,6 +966,13 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
     int r = unet_fwd(c, nullptr, max_unet_rows, 0, nullptr, false, 0, nullptr);
     if (r) return r;
     ppeak = c->persist.peak; tpeak = c->temp.peak;
+  }
+  if (!c->clip.layers.empty()) {
+    c->persist.reset(); c->temp.reset(); c->persist.peak = 0; c->temp.peak = 0;
+    int r = clip_fwd(c, nullptr, c->rows_ident_n, nullptr);
+    if (r) return r;
+    if (c->persist.peak > ppeak) ppeak = c->persist.peak;
+    if (c->temp.peak > tpeak) tpeak = c->temp.peak;
   }
   if (max_vae_images > 0) {
     const int S = g.sample_size, F = 1 << (g.vae_n_blocks - 1);
@@ -951,7 +1006,7 @@ void pnpi_destroy(pnpi_ctx* c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->st);
   void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial,
-                  c->temb_table, c->temb_h, c->temb_emb, c->bias_eff};
+                  c->temb_table, c->temb_h, c->temb_emb, c->bias_eff, c->rows_ident};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
@@ -964,6 +1019,7 @@ int pnpi_load_weights(pnpi_ctx* c, const pnpi_named_tensor* ts, int n) {
     // diffusers 0.3-0.10 register the stride-2 conv twice ("conv" and "Conv2d_0"): accept either spelling
     size_t pos = name.find(".downsamplers.0.Conv2d_0.");
     if (pos != std::string::npos) name.replace(pos, strlen(".downsamplers.0.Conv2d_0."), ".downsamplers.0.conv.");
+    if (name.compare(0, 16, "clip.text_model.") == 0) name = "clip." + name.substr(16);   // transformers < 5 key spelling
     auto it = c->slots.find(name);
     if (it == c->slots.end()) continue;  // unknown keys are ignored (e.g. buffers)
     Slot& s = it->second;
@@ -987,7 +1043,7 @@ int pnpi_missing_weights(const pnpi_ctx* c, char* names_out, size_t cap) {
   size_t used = 0;
   if (names_out && cap) names_out[0] = 0;
   for (auto& kv : c->slots)
-    if (!kv.second.loaded) {
+    if (!kv.second.loaded && kv.first.compare(0, 5, "clip.") != 0) {   // the text encoder reports through pnpi_text_encode
       ++missing;
       if (names_out && used + kv.first.size() + 2 < cap) {
         memcpy(names_out + used, kv.first.c_str(), kv.first.size());
@@ -1057,8 +1113,16 @@ int pnpi_profile_end(pnpi_ctx* c, pnpi_kernel_stats* out) {
   return 0;
 }
 
-static int check_ready(pnpi_ctx* c) {
-  for (auto& kv : c->slots) if (!kv.second.loaded) { c->err = "weights not loaded: " + kv.first; return PNPI_ESTATE; }
+static bool is_clip_slot(const std::string& name) { return name.compare(0, 5, "clip.") == 0; }
+static int check_ready(pnpi_ctx* c) {   // UNet / VAE entry points: the text encoder's weights are optional for them
+  for (auto& kv : c->slots)
+    if (!kv.second.loaded && !is_clip_slot(kv.first)) { c->err = "weights not loaded: " + kv.first; return PNPI_ESTATE; }
+  return 0;
+}
+static int check_clip_ready(pnpi_ctx* c) {
+  if (c->clip.layers.empty()) return fail(c, PNPI_ESTATE, "this context was built without a text encoder (clip_layers = 0)");
+  for (auto& kv : c->slots)
+    if (!kv.second.loaded && is_clip_slot(kv.first)) { c->err = "weights not loaded: " + kv.first; return PNPI_ESTATE; }
   return 0;
 }
 
@@ -1183,6 +1247,57 @@ int pnpi_prox_threshold(pnpi_ctx* c, const float* eps, int nimg, int rpi, size_t
   if (r == -6) return fail(c, PNPI_ESHAPE, "proximal threshold: more than 32768 elements per image");
   CK(r);
   return 0;
+}
+
+// CLIPTextModel.forward -> last_hidden_state (transformers modeling_clip.py: CLIPTextEmbeddings, CLIPEncoderLayer x L with a
+// causal mask, final_layer_norm); pre-LN blocks, quick_gelu MLP.  ids: device int32 [n][T]; out fp32 [n][T][H].
+static int clip_fwd(pnpi_ctx* c, const int* ids, int n, float* out) {
+  const ClipW& t = c->clip;
+  const int H = t.H, T = t.T, M = n * T, dh = H / t.heads;
+  c->persist.reset(); c->temp.reset();
+  half_t* x = palloc(c, (size_t)M * H);
+  if (!c->dry) CK(launch_embed_tokens(ids, M, T, H, t.vocab, t.tok, t.pos, x, c->st));
+  const int ldv = round_up_i(T, 8);
+  for (const ClipLayerW& L : t.layers) {
+    const size_t mk = c->temp.mark();
+    half_t* h1 = talloc(c, (size_t)M * H);
+    if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)H * 2.0, launch_layernorm(x, M, H, 1e-5f, L.ln1.g, L.ln1.b, h1, c->st));
+    half_t* qk = talloc(c, (size_t)M * 2 * H);
+    half_t* vt = talloc(c, (size_t)n * H * ldv);
+    {
+      VtOut v; v.outT = vt; v.col0 = 2 * H; v.ld = ldv; v.f32 = 0; v.rpb = T;
+      CK(op_gemm(c, h1, H, M, H, L.w_qkv, H, 3 * H, L.b_qkv, nullptr, 0, qk, 2 * H, 1.f, &v));
+    }
+    half_t* ao = talloc(c, (size_t)M * H);
+    {
+      AttnP a; a.q = qk; a.ldq = 2 * H; a.q_off = 0; a.k = qk; a.ldk = 2 * H; a.k_off = H; a.vt = vt; a.ldv = ldv;
+      a.o = ao; a.ldo = H; a.heads = t.heads; a.Nq = T; a.Nk = T; a.Dp = dh; a.dh = dh; a.scale = 1.0f / sqrtf((float)dh);
+      a.rows = c->rows_ident; a.nrows = n; a.causal = 1;
+      if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * n * t.heads * (double)T * T * dh, 0.0, T, T, dh, launch_attn_flash(a, c->st));
+    }
+    half_t* x1 = talloc(c, (size_t)M * H);
+    CK(op_gemm(c, ao, H, M, H, L.out.w, H, H, L.out.b, x, H, x1, H));
+    half_t* h2 = talloc(c, (size_t)M * H);
+    if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)H * 2.0, launch_layernorm(x1, M, H, 1e-5f, L.ln2.g, L.ln2.b, h2, c->st));
+    half_t* f = talloc(c, (size_t)M * t.I);
+    CK(op_gemm(c, h2, H, M, H, L.fc1.w, H, t.I, L.fc1.b, nullptr, 0, f, t.I));
+    if (!c->dry) CK(launch_quick_gelu(f, (size_t)M * t.I, c->st));
+    CK(op_gemm(c, f, t.I, M, t.I, L.fc2.w, t.I, H, L.fc2.b, x1, H, x, H));    // x <- x1 + mlp (x's old value is dead)
+    c->temp.release(mk);
+  }
+  half_t* y = palloc(c, (size_t)M * H);
+  if (!c->dry) {
+    PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)H * 2.0, launch_layernorm(x, M, H, 1e-5f, t.final_ln.g, t.final_ln.b, y, c->st));
+    CK(launch_f16_to_f32(y, (size_t)M * H, out, c->st));
+  }
+  return 0;
+}
+
+int pnpi_text_encode(pnpi_ctx* c, const int32_t* input_ids, int n, float* hidden_out) {
+  if (!c || !input_ids || !hidden_out || n <= 0) return PNPI_EINVAL;
+  CKP(check_clip_ready(c));
+  if (n > c->rows_ident_n) return fail(c, PNPI_EINVAL, "more prompts than max(max_unet_rows, 8)");
+  return clip_fwd(c, (const int*)input_ids, n, hidden_out);
 }
 
 // ---- level 2 loops. Scratch for the loops lives at the top of the controller arena (after the controller tables).

@@ -103,6 +103,13 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r)
           if (kv0 + st * 32 + acc_row(r, lane) >= p.Nk) s[st][r] = -INFINITY;
     }
+    if (p.causal) {   // wave-uniform flag: key j > query i is masked (every query keeps key 0, so the running max stays finite)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + st * 32 + acc_row(r, lane) > qtok) s[st][r] = -INFINITY;
+    }
     float mloc = s[0][0];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
@@ -330,7 +337,7 @@ int launch_attn_flash(const AttnP& p, hipStream_t st) {
   const int total = ((p.Nq + 127) / 128) * p.heads * p.nrows;
   dim3 grid((unsigned)(((total + 7) / 8) * 8), 1, 1);
   static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
-  if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma) {
+  if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma && !p.causal) {
     attn_flash_dma64_kernel<<<grid, 256, 0, st>>>(p);
     return (int)hipGetLastError();
   }

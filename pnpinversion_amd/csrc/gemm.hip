@@ -314,7 +314,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// ABL: 0 = product kernel; 1 = DMA only (no fragment reads / MFMA); 2 = compute only (no DMA) -- bottleneck ablations for tools/.
+// ABL: 0 = product kernel; 1 = DMA only (no fragment reads / MFMA); 2 = compute only (no DMA); 3 = activation operand loaded for
+// the first filter tap only -- bottleneck ablations for tools/ (1-3 produce garbage).
 template <int BM, int BN, int BKT, int NST, int ABL = 0>
 __global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   static_assert(BKT == 64 || BKT == 32, "BKT");
@@ -428,10 +429,12 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma
       }
       retap = false;
     }
+    if (ABL != 3 || (is_tap == 0)) {   // ABL 3: the activation operand only for the first filter tap (bound of tap-reuse schemes)
 #pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)a_cur[i], (lds_ptr_t)(sA + (wave * AV + i) * 1024), 16, 0, 0);
-      a_cur[i] += BKT;
+      for (int i = 0; i < AV; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)a_cur[i], (lds_ptr_t)(sA + (wave * AV + i) * 1024), 16, 0, 0);
+        a_cur[i] += BKT;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
@@ -781,6 +784,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
         case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
         case 11: r = launch_dma<128, 128, 32, 3, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
         case 12: r = launch_dma<128, 128, 32, 3, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
+        case 15: r = launch_dma<128, 128, 32, 3, 3>(p, grid, st, g_zero_page); break;   // ablation: activation loads for tap 0 only
         case 13: r = launch_dma<128, 128, 64, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only, 128-byte rows
         case 14: r = launch_dma<128, 128, 64, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only, 128-byte rows
         default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;

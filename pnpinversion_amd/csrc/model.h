@@ -109,6 +109,19 @@ struct VaeW {
   NormW d_norm_out;
 };
 
+struct ClipLayerW {
+  NormW ln1, ln2;
+  half_t* w_qkv; float* b_qkv;   // [3H][H] fused q | k | v (+ biases)
+  LinW out, fc1, fc2;
+};
+struct ClipW {
+  int H = 0, heads = 0, I = 0, vocab = 0, T = 0;
+  half_t* tok = nullptr;         // [vocab][H]
+  half_t* pos = nullptr;         // [T][H]
+  std::vector<ClipLayerW> layers;
+  NormW final_ln;
+};
+
 struct Tensor4 { half_t* p; int B, H, W, C; };
 
 struct CtrlDev {
@@ -156,6 +169,9 @@ struct pnpi_ctx {
   std::unordered_map<std::string, Slot> slots;
   UNetW unet;
   VaeW vae;
+  ClipW clip;
+  int* rows_ident = nullptr;   // [max(max_rows, 8)][4] identity attention-row table (text encoder)
+  int rows_ident_n = 0;
   std::vector<float> ac;
   float final_alpha;
   bool sched_set;

@@ -556,3 +556,44 @@ int launch_repack_vec(const void* src, int src_f16, int n, float* dst, hipStream
   repack_vec_kernel<<<blocks, 256, 0, st>>>(src, src_f16, n, dst, ilv_half);
   return (int)hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// CLIP text encoder helpers (transformers CLIPTextEmbeddings; quick_gelu = x * sigmoid(1.702 x))
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void embed_tokens_kernel(const int* __restrict__ ids, int M, int T, int H, int vocab, const half_t* __restrict__ tok,
+                                    const half_t* __restrict__ pos, half_t* __restrict__ out) {
+  const size_t total = (size_t)M * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / H), c = (int)(i - (size_t)m * H);
+    int id = ids[m];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    out[i] = (half_t)((float)tok[(size_t)id * H + c] + (float)pos[(size_t)(m % T) * H + c]);
+  }
+}
+int launch_embed_tokens(const int* ids, int M, int T, int H, int vocab, const half_t* tok_emb, const half_t* pos_emb, half_t* out,
+                        hipStream_t st) {
+  const size_t total = (size_t)M * H;
+  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  embed_tokens_kernel<<<blocks, 256, 0, st>>>(ids, M, T, H, vocab, tok_emb, pos_emb, out);
+  return (int)hipGetLastError();
+}
+__global__ void quick_gelu_kernel(half_t* __restrict__ x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = (float)x[i];
+    x[i] = (half_t)(v / (1.f + __expf(-1.702f * v)));
+  }
+}
+int launch_quick_gelu(half_t* x, size_t n, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  quick_gelu_kernel<<<blocks, 256, 0, st>>>(x, n);
+  return (int)hipGetLastError();
+}
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+int launch_f16_to_f32(const half_t* in, size_t n, float* out, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  f16_to_f32_kernel<<<blocks, 256, 0, st>>>(in, n, out);
+  return (int)hipGetLastError();
+}

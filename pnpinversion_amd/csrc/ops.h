@@ -64,6 +64,11 @@ int launch_img_u8_to_nhwc(const uint8_t* img, int n, int HW, int Cp, half_t* out
 int launch_dec_to_u8(const float* nchw, int n, int HW, uint8_t* out_hwc, hipStream_t st);
 int launch_scale_f32(const float* in, size_t n, float s, float* out, hipStream_t st);
 int launch_gather_rows_f32(const float* in, const int* rows, int nrows, size_t row_elems, float* out, hipStream_t st);
+// CLIP text embeddings: out[m][:] = fp16(tok_emb[ids[m]] + pos_emb[m % T]); quick_gelu in place; fp16 -> fp32
+int launch_embed_tokens(const int* ids, int M, int T, int H, int vocab, const half_t* tok_emb, const half_t* pos_emb, half_t* out,
+                        hipStream_t st);
+int launch_quick_gelu(half_t* x, size_t n, hipStream_t st);
+int launch_f16_to_f32(const half_t* in, size_t n, float* out, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Attention
@@ -77,6 +82,7 @@ struct AttnP {
   float scale;
   const int* rows;                // device [nrows][4] = {out_row, q_row, k_row, v_row}
   int nrows;
+  int causal = 0;                 // 1: key j is masked for query i when j > i (CLIP text encoder)
 };
 int launch_attn_flash(const AttnP& p, hipStream_t st);
 

@@ -115,10 +115,11 @@ class NativeEngine:
         return t.to(device=self.device, dtype=torch.float32).contiguous()
 
     # ---- weights
-    def load_state_dict(self, unet_sd=None, vae_sd=None, chunk_bytes=1 << 30):
-        """diffusers-layout state dicts (CPU or GPU tensors, fp32 or fp16); repacked on the device into the fp16 arena."""
+    def load_state_dict(self, unet_sd=None, vae_sd=None, chunk_bytes=1 << 30, clip_sd=None):
+        """diffusers-layout state dicts (CPU or GPU tensors, fp32 or fp16); repacked on the device into the fp16 arena.
+        clip_sd: transformers CLIPTextModel state dict (optional; only pnpi_text_encode needs it)."""
         items = []
-        for prefix, sd in (("unet.", unet_sd), ("vae.", vae_sd)):
+        for prefix, sd in (("unet.", unet_sd), ("vae.", vae_sd), ("clip.", clip_sd)):
             if sd:
                 items += [(prefix + k, v) for k, v in sd.items()]
         batch, keep, size = [], [], 0
@@ -196,6 +197,17 @@ class NativeEngine:
         arr = _desc_array(ctrls)
         self._call("pnpi_unet_forward", _p(lat), rows, rows_per_image, int(t), _p(ctx), arr, int(cur_step), _p(out))
         self._keep = (lat, ctx, arr, ctrls)
+        return out
+
+    def text_encode(self, input_ids):
+        """CLIPTextModel(input_ids)[0] on the device: int ids [n, 77] -> fp32 [n, 77, cross_dim]"""
+        ids = torch.as_tensor(input_ids).to(self.device, dtype=torch.int32).contiguous()
+        n, T = ids.shape
+        if T != self.cfg.ctx_len:
+            raise ValueError("input_ids must have %d positions" % self.cfg.ctx_len)
+        out = torch.empty(n, T, self.cfg.cross_dim, device=self.device)
+        self._call("pnpi_text_encode", _p(ids), n, _p(out))
+        self._keep = ids
         return out
 
     def local_blend(self, latents, step_index):

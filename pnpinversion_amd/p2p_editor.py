@@ -30,11 +30,14 @@ class P2PEditor:
         if pipeline is None:
             # The reference loads CompVis/stable-diffusion-v1-4 here (models/p2p_editor.py:23-24).  No checkpoint / network
             # exists on the target boxes: weights are either passed in (diffusers-layout state dicts) or seeded-synthetic.
+            # state_dicts = (unet, vae[, clip_text_model]); with the CLIP text model's weights (or synthetic ones) prompts are
+            # embedded by the device text transformer, as the reference's pipeline.text_encoder does
             if state_dicts is not None:
-                pipeline = NativePipeline(cfg, device=device)
-                pipeline.load_state_dict(*state_dicts)
+                native_text = len(state_dicts) > 2 and state_dicts[2] is not None
+                pipeline = NativePipeline(cfg, device=device, text_encoder="native" if native_text else None)
+                pipeline.load_state_dict(state_dicts[0], state_dicts[1], clip_sd=state_dicts[2] if native_text else None)
             else:
-                pipeline = NativePipeline.synthetic(cfg, seed=weight_seed, device=device)
+                pipeline = NativePipeline.synthetic(cfg, seed=weight_seed, device=device, text_encoder="native")
         self.ldm_stable = pipeline
         self.scheduler = pipeline.scheduler
         # lock-step schedule (pnpi_direct_edit): offsets + reconstruction pass + edit pass share one UNet launch per timestep.

@@ -80,14 +80,32 @@ class NativeUNet:
         return {"sample": eps}
 
 
+class NativeTextEncoder:
+    """`model.text_encoder(input_ids)[0]` (inversion.py:290-306) on the device: the CLIP text transformer of libpnpi."""
+
+    def __init__(self, engine: NativeEngine):
+        self.engine = engine
+        self.device = engine.device
+
+    def to(self, device):
+        return self
+
+    def __call__(self, input_ids, **kw):
+        return (self.engine.text_encode(input_ids),)
+
+
 class NativePipeline:
     def __init__(self, cfg: ModelConfig = SD1, device=None, max_unet_rows=12, max_vae_images=2, tokenizer=None, text_encoder=None,
                  scheduler=None):
+        """text_encoder: None = seeded stand-in embedding (no CLIP weights needed); "native" = the CLIP text transformer of
+        libpnpi (load its weights with load_state_dict(..., clip_sd=...)); or any callable with the CLIPTextModel protocol."""
         self.engine = NativeEngine(cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images)
         self.device = self.engine.device
         self.unet = NativeUNet(self.engine)
         self.vae = NativeVAE(self.engine)
         self.tokenizer = tokenizer or WordTokenizer()
+        if isinstance(text_encoder, str) and text_encoder == "native":
+            text_encoder = NativeTextEncoder(self.engine)
         self.text_encoder = text_encoder or SyntheticTextEncoder(cfg.cross_dim, device=self.device)
         self.scheduler = scheduler or DDIMSchedulerDev(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                                        clip_sample=False, set_alpha_to_one=False)
@@ -96,8 +114,8 @@ class NativePipeline:
     def to(self, device):
         return self
 
-    def load_state_dict(self, unet_sd, vae_sd):
-        self.engine.load_state_dict(unet_sd, vae_sd)
+    def load_state_dict(self, unet_sd, vae_sd, clip_sd=None):
+        self.engine.load_state_dict(unet_sd, vae_sd, clip_sd=clip_sd)
         n, names = self.engine.missing_weights()
         if n:
             raise RuntimeError("missing %d weight tensors, e.g. %s" % (n, names[:5]))
@@ -107,5 +125,6 @@ class NativePipeline:
         """Seeded random-weight pipeline (no checkpoints exist on the build / GPU boxes)."""
         from . import weights
         p = cls(cfg, **kw)
-        p.load_state_dict(weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed))
+        clip = weights.clip_state_dict(cfg, seed) if isinstance(p.text_encoder, NativeTextEncoder) else None
+        p.load_state_dict(weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed), clip_sd=clip)
         return p

@@ -3,8 +3,10 @@
 The reference uses transformers' CLIPTokenizer + CLIPTextModel of the SD-1.4 checkpoint (models/p2p/inversion.py:291-306).
 Neither the CLIP vocabulary nor any checkpoint exists on the build / GPU boxes, so this module provides seeded stand-ins with
 the same interface (what models/p2p/* and utils/utils.py actually touch: `encode`, `decode`, `__call__`, `model_max_length`;
-`text_encoder(ids)[0]`).  With a real checkpoint directory the CLIP classes are used instead (PyTorch-ROCm; text encoding is
-~0.02 % of the FLOPs of one edit and runs once per prompt)."""
+`text_encoder(ids)[0]`).  The text TRANSFORMER itself is native (pipeline.NativeTextEncoder -> pnpi_text_encode: transformers'
+CLIPTextModel on the device, weights in its state-dict layout); what has no offline source is the BPE vocabulary, so the
+tokenizer stays this word-level stand-in (with a real checkpoint directory pass transformers' CLIPTokenizer as `tokenizer`).
+SyntheticTextEncoder is the weight-free stand-in used by the golden fixtures."""
 import zlib
 
 import numpy as np

@@ -166,3 +166,25 @@ def synth_context(cfg: ModelConfig, rows, seed=0, name="context"):
     """Stand-in text-encoder output [rows, ctx_len, cross_dim] (fp16-representable), LayerNorm-like statistics."""
     a = _gen(seed, name).standard_normal((rows, cfg.ctx_len, cfg.cross_dim)).astype(np.float32)
     return torch.from_numpy(_fp16_round(a))
+
+
+def clip_state_dict(cfg: ModelConfig, seed=0):
+    """transformers CLIPTextModel state dict (key names of transformers >= 5; older releases prefix them with "text_model."),
+    seeded, fp16-representable.  Scales follow the HF initialisation loosely; values only need to keep activations O(1)."""
+    sd = {}
+    H, I = cfg.cross_dim, cfg.clip_intermediate
+    e = _gen(seed, "clip.tok").standard_normal((cfg.clip_vocab, H)).astype(np.float32) * 0.02
+    sd["embeddings.token_embedding.weight"] = torch.from_numpy(_fp16_round(e))
+    e = _gen(seed, "clip.pos").standard_normal((cfg.ctx_len, H)).astype(np.float32) * 0.02
+    sd["embeddings.position_embedding.weight"] = torch.from_numpy(_fp16_round(e))
+    for l in range(cfg.clip_layers):
+        pre = "encoder.layers.%d" % l
+        _norm(sd, seed, "clip." + pre + ".layer_norm1", H)
+        _norm(sd, seed, "clip." + pre + ".layer_norm2", H)
+        for n in ("q_proj", "k_proj", "v_proj"):
+            _lin(sd, seed, "clip." + pre + ".self_attn." + n, H, H, gain=1.2)
+        _lin(sd, seed, "clip." + pre + ".self_attn.out_proj", H, H, gain=0.5)
+        _lin(sd, seed, "clip." + pre + ".mlp.fc1", H, I)
+        _lin(sd, seed, "clip." + pre + ".mlp.fc2", I, H, gain=0.5)
+    _norm(sd, seed, "clip.final_layer_norm", H)
+    return {(k[5:] if k.startswith("clip.") else k): v for k, v in sd.items()}

@@ -115,9 +115,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    pipe = MasaCtrlPipeline(SD1, device="cuda:%d" % local_rank)
+    pipe = MasaCtrlPipeline(SD1, device="cuda:%d" % local_rank, text_encoder="native")
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(SD1, 0), weights.vae_state_dict(SD1, 0))
+        pipe.load_state_dict(weights.unet_state_dict(SD1, 0), weights.vae_state_dict(SD1, 0), clip_sd=weights.clip_state_dict(SD1, 0))
     if world > 1:
         broadcast_weights(pipe.engine, src=0)
     editor = MasaCtrlEditor(args.edit_method_list, torch.device("cuda", local_rank), pipeline=pipe)

@@ -59,9 +59,10 @@ def main(argv=None):
     from pnpinversion_amd.config import SD1, SMALL64
     from pnpinversion_amd.pipeline import NativePipeline
     cfg = SD1 if args.model_config == "sd1" else SMALL64
-    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 * max(1, args.batch_size))
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 * max(1, args.batch_size), text_encoder="native")
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0))   # no SD checkpoint offline
+        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0),
+                             clip_sd=weights.clip_state_dict(cfg, 0))                              # no SD checkpoint offline
     if world > 1:
         broadcast_weights(pipe.engine, src=0)
     editor = P2PEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=args.num_ddim_steps, pipeline=pipe)

@@ -21,6 +21,7 @@ def tiny_config(sample_size=16, boc=(32, 64, 64, 64), vae_boc=(32, 32, 64, 64), 
     cfg.cross_dim = cross_dim
     cfg.layers_per_block = layers
     cfg.vae_layers_per_block = layers
+    cfg.clip_layers = 0            # kernel-level tests: no text encoder in the context
     return cfg
 
 

@@ -138,3 +138,41 @@ def test_weight_arena_broadcast_over_rccl_world1():
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny", TINY16), ("sd1", SD1)])
+def test_clip_text_encoder_against_transformers_golden(name, cfg):
+    """pnpi_text_encode (A1: model.text_encoder(ids)[0], inversion.py:290-306) vs transformers' CLIPTextModel on the same seeded
+    weights (tests/golden/clip_*.npz): rel-L2 <= 4e-3 (fp16 activations, fp32 accumulation / softmax / LayerNorm statistics)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_%s.npz" % name))
+    eng = NativeEngine(cfg, max_unet_rows=1, max_vae_images=0)
+    ids = torch.from_numpy(g["input_ids"])
+    with pytest.raises(Exception, match="weights not loaded: clip"):
+        eng.text_encode(ids)                                   # fails loudly until the clip.* weights are there
+    eng.load_state_dict(clip_sd=weights.clip_state_dict(cfg, int(g["seed"])))
+    out = eng.text_encode(ids)
+    ref = torch.from_numpy(g["hidden"])
+    r = ((out.cpu() - ref).norm() / ref.norm()).item()
+    assert out.shape == ref.shape and r < 4e-3, r
+    # causal: the embedding at position p depends on tokens <= p only
+    ids2 = ids.clone()
+    ids2[:, 40:] = 1234
+    out2 = eng.text_encode(ids2)
+    assert torch.equal(out2[:, :40], out[:, :40]) and not torch.equal(out2[:, 40:], out[:, 40:])
+    eng.close()
+
+
+def test_pipeline_with_native_text_encoder():
+    """NativePipeline(text_encoder="native"): init_prompt's embeddings come from the device CLIP transformer end to end."""
+    from pnpinversion_amd.pipeline import NativePipeline, NativeTextEncoder
+    from pnpinversion_amd.p2p.inversion import DirectInversion
+    pipe = NativePipeline.synthetic(TINY16, seed=1, max_unet_rows=4, max_vae_images=1, text_encoder="native")
+    assert isinstance(pipe.text_encoder, NativeTextEncoder)
+    inv = DirectInversion(pipe, num_ddim_steps=2)
+    inv.init_prompt(["a cat on a chair", "a dog on a chair"])
+    assert inv.context.shape == (4, 77, TINY16.cross_dim) and inv.context.is_cuda
+    assert torch.equal(inv.context[0], inv.context[1]) and not torch.equal(inv.context[2], inv.context[3])
+    ref = sd_oracle.clip_text_forward(weights.clip_state_dict(TINY16, 1), TINY16,
+                                      pipe.tokenizer(["a cat on a chair"], padding="max_length", max_length=77).input_ids)
+    assert ((inv.context[2].cpu() - ref[0]).norm() / ref[0].norm()).item() < 4e-3
+    pipe.engine.close()

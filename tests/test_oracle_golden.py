@@ -218,3 +218,13 @@ def test_proximal_guidance_matches_reference():
     out = po.guidance_forward(unet_fn, x_T, c4, None, ctrl, ts, ac_, ac_[0], 7.5, prox="l0", quantile=0.75)
     assert rel(out, v["l0/edited_latents"]) < 5e-5, rel(out, v["l0/edited_latents"])
     assert rel(torch.from_numpy(v["l1/edited_latents"]), v["l0/edited_latents"]) > 1e-3      # the two variants differ
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny", TINY16), ("sd1", SD1)])
+def test_clip_text_encoder_matches_transformers(name, cfg):
+    """oracle.sd_oracle.clip_text_forward vs transformers CLIPTextModel(input_ids)[0] (tests/golden/clip_*.npz)."""
+    g = load("clip_%s.npz" % name)
+    sd = weights.clip_state_dict(cfg, int(g["seed"]))
+    with torch.no_grad():
+        out = sd_oracle.clip_text_forward(sd, cfg, torch.from_numpy(g["input_ids"]))
+    assert rel(out, g["hidden"]) < 2e-5, rel(out, g["hidden"])
