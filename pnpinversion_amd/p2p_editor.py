@@ -233,11 +233,12 @@ class P2PEditor:
                                             model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1,
                                             offset_scale=offset_scale)
         controller.cur_step += self.num_ddim_steps
+        # host-side panel work while the device is still in the loop (the calls above only enqueue)
+        image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
         noise_loss_list = [nl[i, 0] for i in range(nl.shape[0])]
         reconstruct_latent, latents = lats[0, 0], lats[1, 0]
         reconstruct_image = latent2image(model=model.vae, latents=reconstruct_latent)[0]
         images = latent2image(model=model.vae, latents=latents)
-        image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
         panel = Image.fromarray(np.concatenate((image_instruct, image_gt, reconstruct_image, images[-1]), axis=1))
         if return_stages:
             return panel, dict(x_stars=x_stars, noise_loss_list=noise_loss_list, reconstruct_latent=reconstruct_latent,
