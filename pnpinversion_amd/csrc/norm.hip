@@ -186,17 +186,21 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__
   }
 }
 
+static int gn_small_max() {
+  static const int v = getenv("PNPI_GN_SMALL_MAX") ? atoi(getenv("PNPI_GN_SMALL_MAX")) : 24576;
+  return v;
+}
 static bool gn_small_ok(int C1, int C2, int HW, int G) {
   const int C = C1 + C2, cpg = C / G;
-  return (cpg % 4 == 0) && (C1 % 4 == 0) && ((size_t)HW * cpg <= 24576);
+  return (cpg % 4 == 0) && (C1 % 4 == 0) && ((size_t)HW * cpg <= (size_t)gn_small_max());
 }
 static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                            const float* beta, int silu, half_t* out, hipStream_t st) {
   const int cpg = (C1 + C2) / G;
   static bool attr = false;
   if (!attr) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 2));
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 2));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2));
     attr = true;
   }
   // 1024-thread blocks: each (sample, group) slice is a latency chain load -> reduce -> normalise -> store, and four times
