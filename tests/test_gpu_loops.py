@@ -212,7 +212,7 @@ def test_batched_images_match_single_image_calls():
         p1, s1 = ed.edit_image_directinversion(img, src[i], tgt[i], blend_word=blend[i], eq_params=eq[i], return_stages=True)
         xs = torch.stack([x for x in s1["x_stars"]])[:, 0]
         assert rel(st["x_stars"][:, i], xs) < 5e-3, rel(st["x_stars"][:, i], xs)
-        assert rel(st["reconstruct_latents"][i], s1["reconstruct_latent"]) < 1.5e-2
+        assert rel(st["reconstruct_latents"][i], s1["reconstruct_latent"]) < 3e-2
         # both sides carry the fp16 error of their own tile configurations (24-row vs 12-row launches): twice the one-sided bar
         r, frac = masked_rel(st["latents"][i], s1["latents"], tol_frac=0.01)
         assert frac <= 0.01 and r < 3e-2, (i, r, frac)

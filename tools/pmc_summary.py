@@ -1,7 +1,8 @@
 """Reduce rocprofv3 --pmc counter_collection CSVs (one pass FETCH_SIZE, one pass WRITE_SIZE) to per-kernel HBM-side traffic per
 launch, applying the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports wide coalesced reads by 2x; checked here
 on gn_apply_kernel, which reads exactly what it writes).  Optional third pass (SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE):
-MFMA utilisation = busy cycles summed over SIMDs / (GPU-active cycles x 256 CUs x 4 SIMDs).
+MFMA utilisation = busy cycles summed over all SIMDs / (GPU-active cycles x 256 CUs x 4 SIMDs); GRBM_GUI_ACTIVE comes back
+summed over the 8 XCDs (18.5 cycles per ns of kernel time = 8 x 2.31 GHz), hence the / 8.
 usage: pmc_summary.py fetch.csv write.csv out.json [mfma.csv]"""
 import collections, csv, json, sys
 
@@ -24,10 +25,10 @@ for k in sorted(f, key=lambda k: -f[k][1]):
                          "traffic_bytes": 2 * 1024 * s / n + 1024 * ws / max(wn, 1)}
 if len(sys.argv) > 4:
     busy, act = agg(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES"), agg(sys.argv[4], "GRBM_GUI_ACTIVE")
-    out["mfma_util_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), summed over the kernel's launches"
+    out["mfma_util_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), summed over the kernel's launches"
     for k, v in out["kernels"].items():
         if k in busy and k in act and act[k][1] > 0:
-            v["mfma_util"] = busy[k][1] / (act[k][1] * 1024.0)
+            v["mfma_util"] = busy[k][1] / (act[k][1] / 8.0 * 1024.0)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in list(out["kernels"].items())[:10]:
     print("%-70s n=%6d  fetch %8.2f MB  write %8.2f MB  mfma_util %s" % (k[:70], v["launches"], v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6,
