@@ -98,29 +98,32 @@ class MasaCtrlEditor:
         return (panel, dict(x_stars=latents_list, images=image_masactrl)) if return_stages else panel
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--rerun_exist_images", action="store_true")
     ap.add_argument("--data_path", type=str, default="data")
     ap.add_argument("--output_path", type=str, default="output")
     ap.add_argument("--edit_category_list", nargs="+", type=str, default=[str(i) for i in range(10)])
     ap.add_argument("--edit_method_list", nargs="+", type=str, default=["ddim+masactrl", "directinversion+masactrl"])
-    args = ap.parse_args()
+    ap.add_argument("--model_config", choices=("sd1", "small64"), default="sd1", help="small64: reduced-width test configuration")
+    ap.add_argument("--num_ddim_steps", type=int, default=50)
+    args = ap.parse_args(argv)
     from pnpinversion_amd.distributed import broadcast_weights, shard_items
     from pnpinversion_amd import weights
-    from pnpinversion_amd.config import SD1
+    from pnpinversion_amd.config import SD1, SMALL64
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    pipe = MasaCtrlPipeline(SD1, device="cuda:%d" % local_rank, text_encoder="native")
+    cfg = SD1 if args.model_config == "sd1" else SMALL64
+    pipe = MasaCtrlPipeline(cfg, device="cuda:%d" % local_rank, text_encoder="native")
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(SD1, 0), weights.vae_state_dict(SD1, 0), clip_sd=weights.clip_state_dict(SD1, 0))
+        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0), clip_sd=weights.clip_state_dict(cfg, 0))
     if world > 1:
         broadcast_weights(pipe.engine, src=0)
-    editor = MasaCtrlEditor(args.edit_method_list, torch.device("cuda", local_rank), pipeline=pipe)
+    editor = MasaCtrlEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=args.num_ddim_steps, pipeline=pipe)
     with open(os.path.join(args.data_path, "mapping_file.json")) as f:
         instructions = json.load(f)
     work = [(k, v) for k, v in instructions.items() if v["editing_type_id"] in args.edit_category_list]

@@ -379,3 +379,31 @@ def test_proximal_guidance_against_reference_golden(small64, prox):
     assert rel(st["reconstruct_latent"].cpu()[:1], v[prox + "/reconstruct_latent"][:1]) < 2.5e-2
     other = "l1" if prox == "l0" else "l0"
     assert rel(st["latents"], v[other + "/edited_latents"]) > 3 * r                        # and not the other variant
+
+
+def test_masactrl_driver_cli(tmp_path, capsys):
+    """run_editing_masactrl.py end to end (both methods, native CLIP text encoder) on a 2-image PIE-Bench-shaped directory."""
+    import json
+    from PIL import Image
+    import run_editing_masactrl as drv
+    data, out = tmp_path / "data", tmp_path / "output"
+    (data / "annotation_images" / "1_change").mkdir(parents=True)
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    mapping = {}
+    for i in range(2):
+        rel_path = "1_change/%03d.jpg" % i
+        Image.fromarray(np.roll(img, 23 * i, axis=0)).save(str(data / "annotation_images" / rel_path))
+        mapping["%012d" % i] = {"image_path": rel_path, "original_prompt": "a [cat] sitting on a wooden chair",
+                                "editing_prompt": "a [dog] sitting on a wooden chair", "editing_type_id": "1",
+                                "blended_word": "cat dog", "mask": [0, 50]}
+    (data / "mapping_file.json").write_text(json.dumps(mapping))
+    argv = ["--data_path", str(data), "--output_path", str(out), "--model_config", "small64", "--num_ddim_steps", "6",
+            "--edit_category_list", "1"]
+    drv.main(argv)
+    for m in ("ddim+masactrl", "directinversion+masactrl"):
+        files = sorted((out / m / "annotation_images" / "1_change").glob("*.jpg"))
+        assert [f.name for f in files] == ["000.jpg", "001.jpg"]
+        assert Image.open(str(files[0])).size == (2048, 512)
+    assert capsys.readouterr().out.count("editing image") == 4
+    drv.main(argv)
+    assert capsys.readouterr().out.count("skip image") == 4
