@@ -16,6 +16,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
   e2e_proximal.npz     P2PEditor("negative-prompt-inversion+proximal-guidance") with the sweep script's arguments (l0) and l1
   clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
+  method_dispatch.json P2PEditor.__call__'s routing of its 39 method strings (handler + method-specific arguments)
 """
 import json
 import os
@@ -225,6 +226,44 @@ def variants(steps=2):
     np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
 
 
+ALL_METHODS = (["ddim+p2p", "null-text-inversion+p2p", "null-text-inversion+p2p_a800", "null-text-inversion+p2p_3090",
+                "ablation_null-text-inversion_single_branch+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p"] +
+               ["directinversion+p2p_guidance_%s_%s" % (a, b) for a in ("0", "1", "25", "5", "75") for b in ("1", "5", "25", "75")] +
+               ["null-text-inversion+proximal-guidance", "negative-prompt-inversion+proximal-guidance",
+                "ablation_null-latent-inversion+p2p", "ablation_directinversion_08+p2p", "ablation_directinversion_04+p2p"] +
+               ["ablation_directinversion_interval_%d+p2p" % k for k in (2, 5, 10, 24, 49)] +
+               ["ablation_directinversion_add-target+p2p", "ablation_directinversion_add-source+p2p"])
+
+
+def dispatch():
+    """Which edit_image_* method the reference's P2PEditor.__call__ (models/p2p_editor.py:28-135) routes each of its 39 method
+    strings to, and with which method-specific arguments (run_editing_p2p.py's call arguments)."""
+    ref_shim.install()
+    import models.p2p_editor as pe
+    ed = pe.P2PEditor.__new__(pe.P2PEditor)
+    rec = {}
+    names = [n for n in dir(pe.P2PEditor) if n.startswith("edit_image")]
+    for n in names:
+        def mk(n):
+            def f(*a, **k):
+                keep = {kk: (vv if not isinstance(vv, float) else float(vv)) for kk, vv in k.items()
+                        if kk in ("guidance_scale", "inverse_guidance_scale", "forward_guidance_scale", "scale", "skip_step", "proximal",
+                                  "quantile", "recon_lr", "recon_t", "use_inversion_guidance", "use_reconstruction_guidance", "dilate_mask")}
+                return (n, keep)
+            return f
+        setattr(ed, n, mk(n))
+    for m in ALL_METHODS:
+        r = ed(m, image_path="x", prompt_src="a", prompt_tar="b", guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
+               blend_word=None, eq_params=None, proximal="l0", quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400)
+        rec[m] = {"handler": r[0], "kwargs": r[1]}
+    try:
+        ed("no-such-method", image_path="x", prompt_src="a", prompt_tar="b")
+    except NotImplementedError as e:
+        rec["__unknown__"] = str(e)
+    json.dump(rec, open(os.path.join(OUT, "method_dispatch.json"), "w"), indent=1, sort_keys=True)
+    print("method_dispatch.json", len(rec))
+
+
 def clip_text():
     """transformers CLIPTextModel (the class the reference's pipeline instantiates as model.text_encoder) with the seeded weights
     of weights.clip_state_dict: last_hidden_state for two prompts, reduced (TINY16's) and SD-1.x (ViT-L/14 text tower) sizes."""
@@ -353,7 +392,7 @@ def masactrl(steps=6, start_step=2, start_layer=10):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl", "proximal", "clip"]
+    which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl", "proximal", "clip", "dispatch"]
     if "host" in which:
         host_tables()
     if "models" in which:
@@ -369,3 +408,5 @@ if __name__ == "__main__":
         proximal()
     if "clip" in which:
         clip_text()
+    if "dispatch" in which:
+        dispatch()

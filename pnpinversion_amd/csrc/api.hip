@@ -329,10 +329,8 @@ static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2
   if (c->dry) return 0;
   const bool ok1 = s1.p && s1.rows > 0 && HW % s1.rows == 0 && HW / s1.rows <= 256;
   const bool ok2 = !x2 || (s2.p && s2.rows > 0 && HW % s2.rows == 0 && HW / s2.rows <= 256);
-  if (getenv("PNPI_GN_DEBUG"))
-    fprintf(stderr, "gn C=%d+%d HW=%d s1=(%p,%d) s2=(%p,%d) fused=%d\n", C1, C2, HW, (const void*)s1.p, s1.rows, (const void*)s2.p, s2.rows,
-            (int)(ok1 && ok2));
-  if (ok1 && ok2 && !getenv("PNPI_GN_NOFUSE")) {
+  static const bool gn_nofuse = getenv("PNPI_GN_NOFUSE") != nullptr;   // ablation: always recompute the statistics
+  if (ok1 && ok2 && !gn_nofuse) {
     PROFD(PNPI_KC_GROUPNORM, 0.0, 2.0 * B * HW * (double)(C1 + C2) * 2.0, B * HW, C1 + C2, 1,
           launch_groupnorm_fused(x1, x2, C1, C2, B, HW, G, eps, nw.g, nw.b, silu, out, s1.p, HW / s1.rows, s2.p,
                                  x2 ? HW / s2.rows : 1, c->gn_partial, c->st));

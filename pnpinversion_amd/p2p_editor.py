@@ -72,8 +72,10 @@ class P2PEditor:
                            "ablation_directinversion_interval_49+p2p"):
             skip_step = int(edit_method.split("+")[0].split("_")[-1])
             return self.edit_image_directinversion_skip_step(image_path, prompt_src, prompt_tar, skip_step=skip_step, **kw)
-        if edit_method in ("ablation_directinversion_add-target+p2p", "ablation_directinversion_add-source+p2p"):
-            return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, add_target=True, **kw)
+        if edit_method == "ablation_directinversion_add-target+p2p":
+            return self.edit_image_directinversion_add_target(image_path, prompt_src, prompt_tar, **kw)
+        if edit_method == "ablation_directinversion_add-source+p2p":
+            return self.edit_image_directinversion_add_source(image_path, prompt_src, prompt_tar, **kw)
         if edit_method in ("null-text-inversion+p2p", "null-text-inversion+p2p_a800", "null-text-inversion+p2p_3090",
                            "ablation_null-text-inversion_single_branch+p2p", "null-text-inversion+proximal-guidance",
                            "ablation_null-latent-inversion+p2p"):
@@ -145,6 +147,14 @@ class P2PEditor:
         """models/p2p_editor.py:775-840"""
         sc = [1.0 if i % skip_step == 0 else 0.0 for i in range(self.num_ddim_steps)]
         return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, guidance_scale=guidance_scale, offset_scale=sc, **kw)
+
+    def edit_image_directinversion_add_target(self, image_path, prompt_src, prompt_tar, **kw):
+        """models/p2p_editor.py:842-907: the offset is added to both branches (p2p_guidance_forward.py:119-132)"""
+        return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, add_target=True, **kw)
+
+    def edit_image_directinversion_add_source(self, image_path, prompt_src, prompt_tar, **kw):
+        """models/p2p_editor.py:909-978: the same code path as add_target in the reference"""
+        return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, add_target=True, **kw)
 
     def _plain_p2p(self, forward, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                    self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages):

@@ -40,3 +40,13 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(ImportError):
         _capi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_integration_doc_names_every_symbol():
+    """INTEGRATION.md is the binding guide: every entry point of include/pnpi.h has to appear in it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "pnpi.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    syms = sorted(set(re.findall(r"\b(pnpi_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(syms) >= 39 and not [s for s in syms if s not in doc]
