@@ -98,3 +98,105 @@ class SyntheticTextEncoder:
                 out[b, p] = v
         out = out.astype(np.float16).astype(np.float32)
         return (torch.from_numpy(out).to(self.device),)
+
+
+# ------------------------------------------------------------------------------------------------------------------ CLIP BPE
+def _bytes_to_unicode():
+    """The byte <-> printable-unicode table of GPT-2 / CLIP byte-level BPE."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, [chr(c) for c in cs]))
+
+
+class ClipBPETokenizer:
+    """CLIP's byte-level BPE tokenizer (what the reference gets from transformers' CLIPTokenizer: models/p2p/inversion.py:291-301,
+    utils/utils.py:84-102 use `__call__`, `encode`, `decode`, `model_max_length`), from a checkpoint's vocab.json / merges.txt.
+    Pipeline as in transformers 5.x' tokenizers-backed class: NFC + whitespace collapse + lowercase; split by CLIP's regex;
+    bytes -> unicode symbols; BPE merges by rank with the end-of-word suffix "</w>"; <|startoftext|> ... <|endoftext|>, padded
+    with <|endoftext|>.  Pure Python (host integer work, ~10 tokens per prompt); pinned against transformers' implementation on
+    a synthetic vocabulary in tests/test_host_tables.py (no real vocabulary exists offline)."""
+    model_max_length = 77
+
+    def __init__(self, vocab, merges, unk_token="<|endoftext|>", bos_token="<|startoftext|>", eos_token="<|endoftext|>"):
+        import json
+        import regex
+        if isinstance(vocab, str):
+            vocab = json.load(open(vocab, encoding="utf-8"))
+        if isinstance(merges, str):
+            lines = open(merges, encoding="utf-8").read().split("\n")
+            merges = [tuple(l.split()) for l in lines if l and not l.startswith("#version")]
+        self.encoder = dict(vocab)
+        self.decoder = {i: t for t, i in self.encoder.items()}
+        self.ranks = {tuple(m) if not isinstance(m, str) else tuple(m.split()): i for i, m in enumerate(merges)}
+        self.b2u = _bytes_to_unicode()
+        self.u2b = {u: b for b, u in self.b2u.items()}
+        self.bos_token_id, self.eos_token_id = self.encoder[bos_token], self.encoder[eos_token]
+        self.unk_token_id = self.encoder[unk_token]
+        self.pad_token_id = self.eos_token_id
+        self._pat = regex.compile(r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""")
+        self._ws = regex.compile(r"\s+")
+        self._cache = {}
+
+    def _bpe(self, piece):
+        if piece in self._cache:
+            return self._cache[piece]
+        word = list(piece[:-1]) + [piece[-1] + "</w>"]
+        while len(word) > 1:
+            pairs = [(self.ranks.get((word[i], word[i + 1]), 1 << 60), i) for i in range(len(word) - 1)]
+            rank, at = min(pairs)
+            if rank == 1 << 60:
+                break
+            first, second = word[at], word[at + 1]
+            out, i = [], 0
+            while i < len(word):
+                if i < len(word) - 1 and word[i] == first and word[i + 1] == second:
+                    out.append(first + second)
+                    i += 2
+                else:
+                    out.append(word[i])
+                    i += 1
+            word = out
+        self._cache[piece] = word
+        return word
+
+    def _tokenize(self, text):
+        import unicodedata
+        text = self._ws.sub(" ", unicodedata.normalize("NFC", text)).lower()
+        ids = []
+        for piece in self._pat.findall(text):
+            if piece in ("<|startoftext|>", "<|endoftext|>"):
+                ids.append(self.encoder[piece])
+                continue
+            sym = "".join(self.b2u[b] for b in piece.encode("utf-8"))
+            ids += [self.encoder.get(tok, self.unk_token_id) for tok in self._bpe(sym)]
+        return ids
+
+    def encode(self, text, max_length=None):
+        ids = self._tokenize(text)
+        if max_length is not None:
+            ids = ids[: max_length - 2]
+        return [self.bos_token_id] + ids + [self.eos_token_id]
+
+    def decode(self, ids):
+        toks = [self.decoder.get(int(i), "") for i in (ids.tolist() if hasattr(ids, "tolist") else ids)]
+        text = "".join(toks)
+        data = bytearray()
+        for ch in text.replace("</w>", " "):
+            data += bytes([self.u2b[ch]]) if ch in self.u2b else ch.encode("utf-8")
+        return data.decode("utf-8", errors="replace").strip()
+
+    def __call__(self, texts, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
+        if isinstance(texts, str):
+            texts = [texts]
+        L = max_length or self.model_max_length
+        rows = []
+        for t in texts:
+            ids = self.encode(t, max_length=L if truncation else None)
+            rows.append(ids + [self.pad_token_id] * (L - len(ids)) if padding == "max_length" else ids)
+        return WordTokenizer._Out(torch.tensor(rows, dtype=torch.int64))

@@ -114,3 +114,38 @@ def test_method_dispatch_matches_reference():
             if m == "negative-prompt-inversion+p2p" and k not in ("guidance_scale", "proximal"):
                 continue          # the reference forwards the sweep's recon_* / quantile here too; with proximal=None they are inert
             assert k in kw and kw[k] == v, (m, k, kw.get(k), v)
+
+
+def test_clip_bpe_tokenizer_matches_transformers():
+    """text.ClipBPETokenizer vs transformers' CLIPTokenizer on the same (synthetic) vocabulary and merge list: ids, padding,
+    truncation, decode of single tokens (what utils.get_word_inds relies on)."""
+    transformers = pytest.importorskip("transformers")
+    from pnpinversion_amd.text import ClipBPETokenizer, _bytes_to_unicode
+    syms = list(_bytes_to_unicode().values())
+    vocab = syms + [s + "</w>" for s in syms]
+    merges = [("c", "a"), ("ca", "t</w>"), ("d", "o"), ("do", "g</w>"), ("t", "h"), ("th", "e</w>"), ("s", "i"), ("si", "t"), ("sit", "t"),
+              ("i", "n"), ("in", "g</w>"), ("sitt", "ing</w>"), ("o", "n</w>"), ("w", "o"), ("wo", "o"), ("woo", "d"), ("wood", "e"),
+              ("woode", "n</w>"), ("c", "h"), ("ch", "a"), ("cha", "i"), ("chai", "r</w>"), ("'", "s</w>"), ("!", "!</w>"), ("Ã", "©</w>"), ("c", "a"), ("ca", "f"), ("caf", "Ã©</w>")]
+    seen, uniq = set(), []
+    for m in merges:
+        if m not in seen:
+            seen.add(m); uniq.append(m)
+    for a, b in uniq:
+        vocab.append(a + b)
+    vocab += ["<|startoftext|>", "<|endoftext|>"]
+    vmap = {t: i for i, t in enumerate(dict.fromkeys(vocab))}
+    ref = transformers.CLIPTokenizer(vocab=vmap, merges=[(a, b) for a, b in uniq])
+    mine = ClipBPETokenizer(vmap, uniq)
+    texts = ["a cat sitting on the wooden chair", "The   CAT's 12 dogs!!", "", "dog", "café on the chair, a (small) cat-dog",
+             " ".join(["sitting"] * 100), "naïve ÅNGSTRÖM x²", "it's we're I'd they'll"]
+    a = ref(texts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    b = mine(texts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    assert a.shape == b.shape == (len(texts), 77)
+    assert (a == b).all(), [(i, a[i][:20].tolist(), b[i][:20].tolist()) for i in range(len(texts)) if not (a[i] == b[i]).all()]
+    for t in texts[:5]:
+        ia, ib = ref.encode(t), mine.encode(t)
+        assert ia == ib
+        for tok in ia[1:-1]:
+            assert ref.decode([tok]) == mine.decode([tok]), (tok, ref.decode([tok]), mine.decode([tok]))
+    # the reference's word-index helper works on it (utils/utils.py:84-102)
+    assert get_word_inds("a cat sitting on the wooden chair", "cat", mine).tolist() == get_word_inds("a cat sitting on the wooden chair", "cat", ref).tolist() == [2]
