@@ -80,12 +80,27 @@ def cpu_baseline(cfg, budget_s=40.0):
                                                              time.perf_counter() - start)}
 
 
+def self_spawn(n):
+    """Re-run this command as n ranks under torch.distributed.run (rendezvous on 127.0.0.1, a free port); returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="process-launch / rendezvous plumbing only, on CPU with gloo (tests)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--batch-images", type=int, default=4,
                     help="after the headline measurement (one image at a time), also time this many images per set of launches "
@@ -98,11 +113,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU), exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` would
+        sys.exit(self_spawn(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     dist = None
+    if args.dry_run:
+        # rendezvous / barrier / max-over-ranks / one-JSON-line plumbing only (CPU, gloo): tests/test_distributed_cpu.py
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "metric": "edited images/sec @ 512x512, 50 DDIM-inv + 50 denoise steps", "value": None,
+                              "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "max_rank_seconds": float(dt.item())}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -10,6 +10,8 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_refine.npz       models/p2p_editor.py P2PEditor("directinversion+p2p") stage outputs, SMALL64, 2+2 steps,
                        AttentionRefine + AttentionReweight + LocalBlend (the PIE-Bench default controller)
   e2e_replace.npz      same with is_replace_controller=True (AttentionReplace), no blend / reweight
+  e2e_insert2/3.npz    same as e2e_refine for prompt pairs whose target INSERTS tokens (refinement mapper -1 / alpha 0 entries)
+  e2e_sd1.npz          same as e2e_refine at the FULL SD-1.x width (the benchmarked configuration), weight seed 0
   e2e_variants.npz     the reference's P2PEditor run on six more method strings that share the loop (ddim+p2p,
                        negative-prompt-inversion+p2p, a vary-guidance, a not_full, a skip_step and the add-target ablation):
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
@@ -106,15 +108,16 @@ def model_goldens():
         print("model goldens", name, "%.1fs" % (time.time() - t0))
 
 
-def e2e(name, is_replace, blend, steps=2):
+def e2e(name, is_replace, blend, steps=2, cfg=SMALL64, seed=2, pair=None):
+    """pair: index into PROMPT_PAIRS (default: 1 for the Replace controller, which needs equal word counts, else 0).  Pairs 2 and
+    3 insert tokens into the target prompt (seq_aligner.get_mapper's -1 / alpha 0 entries).  cfg=SD1 is the benchmarked width."""
     ref_shim.install()
-    cfg = SMALL64
     t0 = time.time()
-    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    usd, vsd = weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed)
     tok = WordTokenizer()
     enc = SyntheticTextEncoder(cfg.cross_dim, seed=7)
     ed = ref_shim.build_editor(cfg, usd, vsd, tok, enc, steps)
-    src, tgt, w0, w1 = PROMPT_PAIRS[1] if is_replace else PROMPT_PAIRS[0]
+    src, tgt, w0, w1 = PROMPT_PAIRS[pair if pair is not None else (1 if is_replace else 0)]
     from PIL import Image
     img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
     stages = {}
@@ -155,7 +158,7 @@ def e2e(name, is_replace, blend, steps=2):
                         context=stages["context"].astype(np.float16), reconstruct_latent=calls[0], edited_latents=calls[1],
                         recon_image_small=panel[::4, 2 * S:3 * S:4], edited_image_small=panel[::4, 3 * S::4],
                         src=src, tgt=tgt, blend=np.array([w0, w1]), steps=np.int64(steps), is_replace=np.bool_(is_replace),
-                        use_blend=np.bool_(blend))
+                        use_blend=np.bool_(blend), weight_seed=np.int64(seed))
     print("e2e", name, "%.1fs" % (time.time() - t0))
 
 
@@ -400,6 +403,13 @@ if __name__ == "__main__":
     if "e2e" in which:
         e2e("refine", False, True)
         e2e("replace", True, False)
+    if "e2e_insert" in which or not sys.argv[1:]:
+        # Refine with INSERTED target tokens (mapper -1 / alphas 0), with and without LocalBlend + Reweight
+        e2e("insert2", False, True, pair=2)
+        e2e("insert3", False, False, pair=3)
+    if "e2e_sd1" in which or not sys.argv[1:]:
+        # the benchmarked configuration: full SD-1.x width (859.5 M parameters), the reference's own P2PEditor, 2 + 2 steps
+        e2e("sd1", False, True, steps=2, cfg=SD1, seed=0)
     if "variants" in which:
         variants()
     if "masactrl" in which:

@@ -5,6 +5,7 @@ loop call of libpnpi (pnpi_edit_loop / pnpi_ddim_invert_cfg); the registered att
 import numpy as np
 import torch
 
+from ..p2p.attention_control import controller_tables
 from ..pipeline import NativePipeline
 
 
@@ -51,7 +52,7 @@ class MasaCtrlPipeline(NativePipeline):
         context = torch.cat([uncond, text])
         self.scheduler.set_timesteps(num_inference_steps)
         ed = self.masactrl_editor
-        tables = ed.tables() if ed is not None and hasattr(ed, "tables") else None
+        tables = controller_tables(ed)
         nl = torch.stack(list(noise_loss_list))[:, None] if noise_loss_list is not None else None
         out = self.engine.edit_loop(latents[:1].reshape(1, *latents.shape[-3:]), context[None], nl,
                                     [tables] if tables is not None else None, self.scheduler.timesteps.numpy(), guidance_scale)

@@ -183,6 +183,18 @@ def make_controller(pipeline, prompts, is_replace_controller, cross_replace_step
     return controller
 
 
+def controller_tables(controller):
+    """Host tables (kernel descriptor) of a registered controller, None for "no edit".  An object without `.tables()` -- e.g. an
+    instance of the reference's own callback classes (models/p2p/attention_control.py:151-363) or of a user subclass of them --
+    would be called at every attention site by the reference; silently ignoring it would be a wrong edit, so it raises."""
+    if controller is None:
+        return None
+    if not hasattr(controller, "tables"):
+        raise TypeError("controller %s has no native descriptor (.tables()); build it with pnpinversion_amd.p2p.attention_control "
+                        "(same class names / arguments as models/p2p/attention_control.py)" % type(controller).__name__)
+    return controller.tables()
+
+
 def register_attention_control(model, controller):
     """The reference patches 32 CrossAttention.forward methods here (attention_control.py:12-81).  The native UNet has no
     Python attention modules; registration just hands the controller to the pipeline's UNet, which turns it into the kernel

@@ -4,7 +4,7 @@ LocalBlend) runs as one device-resident pnpi_edit_loop call."""
 import torch
 
 from ..utils.utils import init_latent
-from .attention_control import register_attention_control
+from .attention_control import controller_tables, register_attention_control
 
 
 def _encode_prompts(model, prompt):
@@ -27,7 +27,7 @@ def _run(model, prompt, controller, latent, num_inference_steps, guidance_scale,
     context = _encode_prompts(model, prompt)
     latent, latents = init_latent(latent, model, height, width, generator, batch_size)
     model.scheduler.set_timesteps(num_inference_steps)
-    tables = controller.tables() if controller is not None and hasattr(controller, "tables") else None
+    tables = controller_tables(controller)
     nl = None
     if noise_loss_list is not None and add_offset:
         nl = torch.stack(list(noise_loss_list))[:, None]               # [steps, 1, 2, 4, h, w]
@@ -84,7 +84,7 @@ def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 5
     if batch_size == 1:   # the kernel batch is [unc_a, unc_b, cond_a, cond_b]: run the single prompt as both rows of a pair
         uncond, text = uncond.expand(2, *uncond.shape[1:]), text.expand(2, *text.shape[1:])
     context = torch.cat([uncond, text])
-    tables = controller.tables() if controller is not None and hasattr(controller, "tables") else None
+    tables = controller_tables(controller)
     if prox is not None and batch_size != 2:
         raise NotImplementedError("the proximal step takes its quantile over the (source, target) pair")
     out = model.engine.edit_loop(latent.reshape(1, *latent.shape[-3:]), context[None], None, [tables] if tables is not None else None,

@@ -69,8 +69,12 @@ class NativeUNet:
         t = int(timestep)
         ctrls, cur_step, rpi = None, 0, 1
         c = self.controller
-        tables = c.tables() if c is not None and hasattr(c, "tables") else None
-        if tables is not None and rows % 4 == 0:
+        from .p2p.attention_control import controller_tables
+        tables = controller_tables(c)        # raises for a controller object the library has no descriptor for
+        if tables is not None:
+            if rows % 4 != 0:
+                raise ValueError("an attention controller is registered: the UNet batch must be [uncond_src, uncond_tgt, cond_src, "
+                                 "cond_tgt] per image (rows %% 4 == 0), got %d rows" % rows)
             ctrls, cur_step, rpi = [tables] * (rows // 4), c.cur_step, 4
         eps = self.engine.unet(sample, t, encoder_hidden_states, rows_per_image=rpi, ctrls=ctrls, cur_step=cur_step)
         if c is not None and hasattr(c, "cur_step"):

@@ -34,11 +34,12 @@ class WordTokenizer:
         return [word[:4], word[4:]] if len(word) > 6 else [word]
 
     def encode(self, text):
-        ids = [BOS]
+        body = []
         for w in text.split(" "):
             if w:
-                ids += [self._piece_id(p) for p in self._pieces(w)]
-        return (ids + [EOS])[: self.model_max_length]
+                body += [self._piece_id(p) for p in self._pieces(w)]
+        # CLIP truncation keeps the EOS token (body cut to max_length - 2), as ClipBPETokenizer.encode does
+        return [BOS] + body[: self.model_max_length - 2] + [EOS]
 
     def decode(self, ids):
         out = []
@@ -62,8 +63,10 @@ class WordTokenizer:
         L = max_length or self.model_max_length
         rows = []
         for t in texts:
-            ids = self.encode(t)[:L]
-            rows.append(ids + [EOS] * (L - len(ids)))
+            ids = self.encode(t)
+            if truncation and len(ids) > L:
+                ids = ids[: L - 1] + [EOS]
+            rows.append(ids + [EOS] * (L - len(ids)) if padding else ids)
         return WordTokenizer._Out(torch.tensor(rows, dtype=torch.int64))
 
 

@@ -87,9 +87,10 @@ def _tables_from_product(g, steps):
     return t
 
 
-@pytest.mark.parametrize("name", ["refine", "replace"])
+@pytest.mark.parametrize("name", ["refine", "replace", "insert2", "insert3"])
 def test_loops_and_controllers_match_reference(name):
-    """The reference's P2PEditor("directinversion+p2p") stage outputs vs the oracle's loops (SMALL64, 2+2 steps)."""
+    """The reference's P2PEditor("directinversion+p2p") stage outputs vs the oracle's loops (SMALL64, 2+2 steps).
+    insert2 / insert3: target prompts that INSERT tokens (refinement mapper -1 entries with alpha 0, seq_aligner.py:107-118)."""
     g = load("e2e_%s.npz" % name)
     cfg, steps = SMALL64, int(g["steps"])
     usd = weights.unet_state_dict(cfg, 2)
@@ -109,7 +110,10 @@ def test_loops_and_controllers_match_reference(name):
         scale = x_stars[0].norm().item() / x_stars[0].numel() ** 0.5
         assert (torch.stack(nl) - torch.from_numpy(g["noise_loss"])).abs().max().item() < 5e-5 * max(1.0, scale)
     nl_ref = [x for x in torch.from_numpy(g["noise_loss"])]
-    ctrl = po.EditController(32, _tables_from_product(g, steps))
+    tables = _tables_from_product(g, steps)
+    if name.startswith("insert"):
+        assert (tables["mapper"] == -1).any() and (tables["alphas"] == 0).any()
+    ctrl = po.EditController(32, tables)
     out = po.guidance_forward(unet_fn, x_stars[-1], ctx, nl_ref, ctrl, ts, ac_, ac_[0], 7.5)
     assert rel(out, g["edited_latents"]) < 5e-5, rel(out, g["edited_latents"])
     # Note D of SURVEY.md: the source branch reproduces x*_0
