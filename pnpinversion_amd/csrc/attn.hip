@@ -561,11 +561,10 @@ static size_t ce_lds_bytes() {
 
 template <int DP>
 static int launch_ce(const CrossEditP& p, hipStream_t st) {
-  static bool attr_set = false;
+  static unsigned long long attr_devs = 0;
   const size_t lds = ce_lds_bytes<DP>();
-  if (!attr_set) {
+  if (first_on_device(attr_devs)) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_cross_edit_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   dim3 grid((p.Nq + 127) / 128, p.heads, p.npairs);
   attn_cross_edit_kernel<DP><<<grid, 256, lds, st>>>(p);

@@ -49,6 +49,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// hipFuncSetAttribute (dynamic-LDS opt-in) is per DEVICE: a process that drives a second device must set it there too.
+// `mask` is a function-local static; returns true the first time the calling thread's current device is seen.
+static inline bool first_on_device(unsigned long long& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  if (mask >> dev & 1ull) return false;
+  mask |= 1ull << dev;
+  return true;
+}
+
 #define HIP_CHECK_RET(expr)                         \
   do {                                              \
     hipError_t _e = (expr);                         \

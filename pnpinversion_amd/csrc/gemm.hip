@@ -646,10 +646,9 @@ static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t
   grid = dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
   constexpr int ring = NST * (BM + BN) * BKT * 2, epi = BM * (BN + 8) * 2 + 4 * BN * 2 * 4;   // the LDS epilogue re-uses the ring
   constexpr int lds = ring > epi ? ring : epi;
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr_devs = 0;
+  if (first_on_device(attr_devs)) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
   }
   igemm_dma_kernel<BM, BN, BKT, NST, ABL><<<grid, 256, lds, st>>>(p, zero_page);
   return 0;

@@ -23,21 +23,31 @@ import torch
 
 
 class P2PEditor:
-    def __init__(self, method_list, device, num_ddim_steps=50, *, pipeline=None, cfg=SD1, weight_seed=0, state_dicts=None):
+    def __init__(self, method_list, device, num_ddim_steps=50, *, pipeline=None, cfg=SD1, weight_seed=0, state_dicts=None,
+                 tokenizer=None, checkpoint_dir=None):
         self.device = device
         self.method_list = method_list
         self.num_ddim_steps = num_ddim_steps
         if pipeline is None:
-            # The reference loads CompVis/stable-diffusion-v1-4 here (models/p2p_editor.py:23-24).  No checkpoint / network
-            # exists on the target boxes: weights are either passed in (diffusers-layout state dicts) or seeded-synthetic.
-            # state_dicts = (unet, vae[, clip_text_model]); with the CLIP text model's weights (or synthetic ones) prompts are
-            # embedded by the device text transformer, as the reference's pipeline.text_encoder does
+            # The reference loads CompVis/stable-diffusion-v1-4 here (models/p2p_editor.py:23-24): `checkpoint_dir` is that
+            # directory in the diffusers layout (unet/, vae/, text_encoder/, tokenizer/ -> checkpoint.load_checkpoint_dir).
+            # Alternatively state_dicts = (unet, vae[, clip_text_model]) with `tokenizer` = the checkpoint's CLIP tokenizer
+            # (text.ClipBPETokenizer(vocab.json, merges.txt) or transformers' CLIPTokenizer).  With neither, seeded synthetic weights
+            # and the word-level stand-in tokenizer (no checkpoint exists on the build / GPU boxes).
+            if checkpoint_dir is not None:
+                from .checkpoint import load_checkpoint_dir
+                unet_sd, vae_sd, clip_sd, ck_tok = load_checkpoint_dir(checkpoint_dir)
+                state_dicts, tokenizer = (unet_sd, vae_sd, clip_sd), tokenizer or ck_tok
             if state_dicts is not None:
                 native_text = len(state_dicts) > 2 and state_dicts[2] is not None
-                pipeline = NativePipeline(cfg, device=device, text_encoder="native" if native_text else None)
+                if native_text and tokenizer is None:
+                    # real CLIPTextModel weights fed with the stand-in tokenizer's hashed ids would embed noise: a silently wrong edit
+                    raise ValueError("CLIP text-encoder weights were supplied without their tokenizer: pass tokenizer= (e.g. "
+                                     "pnpinversion_amd.text.ClipBPETokenizer(vocab.json, merges.txt)) or checkpoint_dir=")
+                pipeline = NativePipeline(cfg, device=device, text_encoder="native" if native_text else None, tokenizer=tokenizer)
                 pipeline.load_state_dict(state_dicts[0], state_dicts[1], clip_sd=state_dicts[2] if native_text else None)
             else:
-                pipeline = NativePipeline.synthetic(cfg, seed=weight_seed, device=device, text_encoder="native")
+                pipeline = NativePipeline.synthetic(cfg, seed=weight_seed, device=device, text_encoder="native", tokenizer=tokenizer)
         self.ldm_stable = pipeline
         self.scheduler = pipeline.scheduler
         # lock-step schedule (pnpi_direct_edit): offsets + reconstruction pass + edit pass share one UNet launch per timestep.

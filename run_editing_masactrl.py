@@ -107,9 +107,10 @@ def main(argv=None):
     ap.add_argument("--edit_method_list", nargs="+", type=str, default=["ddim+masactrl", "directinversion+masactrl"])
     ap.add_argument("--model_config", choices=("sd1", "small64"), default="sd1", help="small64: reduced-width test configuration")
     ap.add_argument("--num_ddim_steps", type=int, default=50)
+    from pnpinversion_amd.checkpoint import add_weight_args, resolve_weights
+    add_weight_args(ap)
     args = ap.parse_args(argv)
     from pnpinversion_amd.distributed import broadcast_weights, shard_items
-    from pnpinversion_amd import weights
     from pnpinversion_amd.config import SD1, SMALL64
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,9 +119,10 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     cfg = SD1 if args.model_config == "sd1" else SMALL64
-    pipe = MasaCtrlPipeline(cfg, device="cuda:%d" % local_rank, text_encoder="native")
+    unet_sd, vae_sd, clip_sd, tokenizer = resolve_weights(args, cfg, rank)     # --checkpoint_dir | --synthetic_weights (loud)
+    pipe = MasaCtrlPipeline(cfg, device="cuda:%d" % local_rank, text_encoder="native", tokenizer=tokenizer)
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0), clip_sd=weights.clip_state_dict(cfg, 0))
+        pipe.load_state_dict(unet_sd, vae_sd, clip_sd=clip_sd)
     if world > 1:
         broadcast_weights(pipe.engine, src=0)
     editor = MasaCtrlEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=args.num_ddim_steps, pipeline=pipe)

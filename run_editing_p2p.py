@@ -12,8 +12,11 @@ import numpy as np
 import torch
 from PIL import Image
 
+from pnpinversion_amd.checkpoint import add_weight_args, resolve_weights
 from pnpinversion_amd.distributed import broadcast_weights, shard_items
 from pnpinversion_amd.p2p_editor import P2PEditor
+
+BATCHED_METHODS = ("directinversion+p2p",)     # methods with a several-images-per-launch entry point (always the lock-step schedule)
 
 
 def mask_decode(encoded_mask, image_shape=(512, 512)):
@@ -47,6 +50,7 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=1, help="images per set of launches and GPU (not in the reference: it edits one by one)")
     ap.add_argument("--model_config", choices=("sd1", "small64"), default="sd1", help="small64: reduced-width test configuration")
     ap.add_argument("--num_ddim_steps", type=int, default=50)
+    add_weight_args(ap)
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,14 +59,19 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from pnpinversion_amd import weights
     from pnpinversion_amd.config import SD1, SMALL64
     from pnpinversion_amd.pipeline import NativePipeline
     cfg = SD1 if args.model_config == "sd1" else SMALL64
-    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 * max(1, args.batch_size), text_encoder="native")
+    unet_sd, vae_sd, clip_sd, tokenizer = resolve_weights(args, cfg, rank)     # --checkpoint_dir | --synthetic_weights (loud)
+    batched = args.batch_size > 1 and any(m in BATCHED_METHODS for m in args.edit_method_list)
+    if args.batch_size > 1:
+        for m in args.edit_method_list:
+            if m not in BATCHED_METHODS:
+                print(f"WARNING: --batch_size {args.batch_size} applies to {BATCHED_METHODS} only; [{m}] is edited one image at a time")
+    pipe = NativePipeline(cfg, device="cuda:%d" % local_rank, max_unet_rows=12 * (args.batch_size if batched else 1),
+                          text_encoder="native", tokenizer=tokenizer)
     if rank == 0:
-        pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0),
-                             clip_sd=weights.clip_state_dict(cfg, 0))                              # no SD checkpoint offline
+        pipe.load_state_dict(unet_sd, vae_sd, clip_sd=clip_sd)
     if world > 1:
         broadcast_weights(pipe.engine, src=0)
     editor = P2PEditor(args.edit_method_list, torch.device("cuda", local_rank), num_ddim_steps=args.num_ddim_steps, pipeline=pipe)
@@ -88,7 +97,7 @@ def main(argv=None):
                 print(f"skip image [{image_path}] with [{method}]")
                 continue
             todo.append((src, tgt, image_path, blended, out_path))
-        nb = args.batch_size if method == "directinversion+p2p" else 1
+        nb = args.batch_size if method in BATCHED_METHODS else 1
         for b0 in range(0, len(todo), nb):
             chunk = todo[b0:b0 + nb]
             for (_, _, image_path, _, _) in chunk:

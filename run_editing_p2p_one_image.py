@@ -4,6 +4,8 @@ import argparse
 
 import torch
 
+from pnpinversion_amd.checkpoint import add_weight_args, resolve_weights
+from pnpinversion_amd.config import SD1
 from pnpinversion_amd.p2p_editor import P2PEditor
 from run_editing_p2p import setup_seed
 
@@ -16,8 +18,12 @@ def main():
     ap.add_argument("--blended_word", type=str, default="cake cake")
     ap.add_argument("--output_path", nargs="+", type=str, default=["directinversion+p2p.jpg"])
     ap.add_argument("--edit_method_list", nargs="+", type=str, default=["directinversion+p2p"])
+    add_weight_args(ap)
     args = ap.parse_args()
-    editor = P2PEditor(args.edit_method_list, torch.device("cuda"))
+    unet_sd, vae_sd, clip_sd, tokenizer = resolve_weights(args, SD1)           # --checkpoint_dir | --synthetic_weights (loud)
+    from pnpinversion_amd.text import WordTokenizer
+    editor = P2PEditor(args.edit_method_list, torch.device("cuda"), state_dicts=(unet_sd, vae_sd, clip_sd),
+                       tokenizer=tokenizer or WordTokenizer())
     blended = args.blended_word.split(" ") if args.blended_word != "" else []
     for method, out_path in zip(args.edit_method_list, args.output_path):
         print(f"editing image [{args.image_path}] with [{method}]")

@@ -27,3 +27,49 @@ def test_mask_decode():
     enc += [512 * 512 - 10, 500]           # run past the end is clipped
     assert np.array_equal(mask_decode(enc), _reference_semantics(enc))
     assert mask_decode([]).sum() == 4 * 512 - 4
+
+
+def test_checkpoint_dir_loader_and_weight_flags(tmp_path):
+    """--checkpoint_dir reads the diffusers layout the reference downloads (models/p2p_editor.py:23-24); neither flag -> refusal;
+    CLIP weights without their tokenizer -> ValueError (hashed stand-in ids into real CLIP weights would be a silently wrong edit)."""
+    import argparse
+    import json
+    import pytest
+    import torch
+    from safetensors.torch import save_file
+    from pnpinversion_amd.checkpoint import add_weight_args, load_checkpoint_dir, resolve_weights
+    from pnpinversion_amd.config import TINY16
+    from pnpinversion_amd.p2p_editor import P2PEditor
+    from pnpinversion_amd.text import ClipBPETokenizer
+    for sub in ("unet", "vae", "text_encoder", "tokenizer"):
+        (tmp_path / sub).mkdir()
+    save_file({"conv_in.weight": torch.ones(2, 2)}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    torch.save({"encoder.conv_in.weight": torch.zeros(3)}, str(tmp_path / "vae" / "diffusion_pytorch_model.bin"))
+    save_file({"text_model.embeddings.position_ids": torch.zeros(1, 77), "text_model.final_layer_norm.weight": torch.ones(4)},
+              str(tmp_path / "text_encoder" / "model.safetensors"))
+    vocab = {"<|startoftext|>": 0, "<|endoftext|>": 1, "a</w>": 2, "c": 3, "at</w>": 4, "cat</w>": 5, "a": 6, "t</w>": 7}
+    (tmp_path / "tokenizer" / "vocab.json").write_text(json.dumps(vocab))
+    (tmp_path / "tokenizer" / "merges.txt").write_text("#version: 0.2\na t</w>\nc at</w>\n")
+    unet, vae, clip, tok = load_checkpoint_dir(str(tmp_path))
+    assert list(unet) == ["conv_in.weight"] and list(vae) == ["encoder.conv_in.weight"]
+    assert list(clip) == ["final_layer_norm.weight"]                       # prefix stripped, position_ids buffer dropped
+    assert isinstance(tok, ClipBPETokenizer) and tok.encode("a cat") == [0, 2, 5, 1]
+    ap = argparse.ArgumentParser()
+    add_weight_args(ap)
+    with pytest.raises(SystemExit, match="--checkpoint_dir"):
+        resolve_weights(ap.parse_args([]), TINY16)
+    with pytest.raises(SystemExit, match="mutually exclusive"):
+        resolve_weights(ap.parse_args(["--checkpoint_dir", str(tmp_path), "--synthetic_weights"]), TINY16)
+    got = resolve_weights(ap.parse_args(["--checkpoint_dir", str(tmp_path)]), TINY16, rank=1)
+    assert got[0] is None and isinstance(got[3], ClipBPETokenizer)          # other ranks receive the arena by broadcast
+    with pytest.raises(ValueError, match="without their tokenizer"):
+        P2PEditor(["directinversion+p2p"], "cuda", state_dicts=({}, {}, {"x": torch.zeros(1)}))
+
+
+def test_word_tokenizer_truncation_keeps_eos():
+    from pnpinversion_amd.text import BOS, EOS, WordTokenizer
+    tok = WordTokenizer()
+    ids = tok.encode(" ".join("w%d" % i for i in range(100)))
+    assert len(ids) == 77 and ids[0] == BOS and ids[-1] == EOS and EOS not in ids[1:-1]
+    rows = tok([" ".join("w%d" % i for i in range(100)), "a b"], padding="max_length", max_length=77).input_ids
+    assert rows.shape == (2, 77) and int(rows[0, -1]) == EOS and int(rows[1, 3]) == EOS

@@ -342,7 +342,7 @@ def test_sweep_driver_cli(tmp_path, capsys):
                                 "editing_prompt": "a [dog] sitting on a wooden chair", "editing_type_id": "0",
                                 "blended_word": "cat dog" if i != 1 else "", "mask": [0, 100, 5000, 300]}
     (data / "mapping_file.json").write_text(json.dumps(mapping))
-    argv = ["--data_path", str(data), "--output_path", str(out), "--model_config", "small64", "--num_ddim_steps", "3",
+    argv = ["--data_path", str(data), "--output_path", str(out), "--model_config", "small64", "--synthetic_weights", "--num_ddim_steps", "3",
             "--batch_size", "2", "--edit_category_list", "0"]
     drv.main(argv)
     files = sorted((out / "directinversion+p2p" / "annotation_images" / "0_random").glob("*.jpg"))
@@ -397,7 +397,7 @@ def test_masactrl_driver_cli(tmp_path, capsys):
                                 "editing_prompt": "a [dog] sitting on a wooden chair", "editing_type_id": "1",
                                 "blended_word": "cat dog", "mask": [0, 50]}
     (data / "mapping_file.json").write_text(json.dumps(mapping))
-    argv = ["--data_path", str(data), "--output_path", str(out), "--model_config", "small64", "--num_ddim_steps", "6",
+    argv = ["--data_path", str(data), "--output_path", str(out), "--model_config", "small64", "--synthetic_weights", "--num_ddim_steps", "6",
             "--edit_category_list", "1"]
     drv.main(argv)
     for m in ("ddim+masactrl", "directinversion+masactrl"):
