@@ -104,6 +104,10 @@ typedef struct {
   uint64_t vae_encodes, vae_decodes;
   double executed_gemm_flops;      /* 2*M*N*K over every MFMA GEMM/conv launch, padding included */
   double executed_attn_flops;
+  uint64_t text_kv_rows;           /* context rows whose 16 cross-attention K / V projections were computed by a precompute (2.95 GFLOP
+                                      each for SD-1.x); a forward that reads the cache does NOT execute them: its sample-forward is
+                                      803.27 - 2.95 GFLOP */
+  uint64_t unet_sample_forwards_cached_kv;   /* of unet_sample_forwards, the rows that read the text K / V cache */
 } pnpi_counters;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
@@ -125,7 +129,8 @@ int pnpi_reset_counters(pnpi_ctx* ctx);
 /* Per-kernel-class timing with HIP events on the ctx stream (used by bench.py for the `roofline` object).
  * Between begin and end every kernel launch of the graph executor is bracketed by two events. */
 enum { PNPI_KC_IGEMM128 = 0, PNPI_KC_IGEMM64 = 1, PNPI_KC_IGEMM64_SPLITK = 2, PNPI_KC_ATTN_FLASH = 3, PNPI_KC_ATTN_EDIT = 4,
-       PNPI_KC_GROUPNORM = 5, PNPI_KC_LAYERNORM = 6, PNPI_KC_GEGLU = 7, PNPI_KC_SOFTMAX = 8, PNPI_KC_COUNT = 9 };
+       PNPI_KC_GROUPNORM = 5, PNPI_KC_LAYERNORM = 6, PNPI_KC_GEGLU = 7, PNPI_KC_SOFTMAX = 8, PNPI_KC_IGEMM_WIDE = 9 /* 128x320, 128x256 tiles */,
+       PNPI_KC_COUNT = 10 };
 typedef struct {
   uint64_t launches;
   double total_ms;      /* sum of per-launch durations */
@@ -139,6 +144,11 @@ int pnpi_profile_end(pnpi_ctx* ctx, pnpi_kernel_stats* out /* [PNPI_KC_COUNT] */
 /* model.unet(latents, t, encoder_hidden_states=context)["sample"]    inversion.py:273, p2p_guidance_forward.py:109 */
 int pnpi_unet_forward(pnpi_ctx* ctx, const float* latents, int rows, int rows_per_image, int t, const float* context,
                       const pnpi_ctrl_desc* ctrl_host /* nullable, [rows/4] */, int cur_step, float* eps_out);
+/* Cross-attention keys / values of the 16 transformer blocks for `rows` context rows (device fp32 [rows][77][768]); they depend on
+ * the text only (CrossAttention.to_k / to_v on encoder_hidden_states, my_diffusers/models/attention.py:230-234, evaluated by the
+ * reference inside every one of its 650 UNet calls per image).  pnpi_unet_forward(..., context = NULL, ...) then reads the cache
+ * (rows must match); the level-2 loops below precompute it themselves once per loop. */
+int pnpi_text_kv_precompute(pnpi_ctx* ctx, const float* context, int rows);
 /* controller.step_callback -> LocalBlend.__call__ (attention_control.py:108-121,253-256) for level-1 drivers:
  * latents [nimg][2][4][h][w] updated in place, using the maps accumulated by the preceding pnpi_unet_forward calls */
 int pnpi_local_blend(pnpi_ctx* ctx, float* latents, int nimg, int step_index);
@@ -210,6 +220,16 @@ int pnpi_direct_edit(pnpi_ctx* ctx, const float* ddim_latents /*[nsteps+1][nimg]
 int pnpi_op_conv(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16, int C1, int C2, int B, int H, int W,
                  int ksize, int stride, int pad, int upsample, int Ho, int Wo, const void* w_f16 /*[N][k*k*(C1+C2)]*/,
                  const float* bias, const void* residual_f16, int N, void* out_nhwc_f16, int force_cfg, int force_split);
+/* pnpi_op_conv + the per-(m-tile, channel) (sum, sum of squares) partials its epilogue produces for the consumer GroupNorm
+ * (replaces the statistics pass of torch.nn.GroupNorm, my_diffusers/models/resnet.py:296): stats_out [ceil(M/tile_rows)][N][2]
+ * fp32 over the stored fp16 values; *tile_rows_out = rows per m-tile, 0 if this launch configuration produced none. */
+int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16, int C1, int C2, int B, int H, int W,
+                       int ksize, int stride, int pad, int upsample, int Ho, int Wo, const void* w_f16, const float* bias,
+                       const void* residual_f16, int N, void* out_nhwc_f16, int force_cfg, int force_split, float* stats_out,
+                       int* tile_rows_out);
+/* process-wide kernel tuning knobs ("igemm_v320", "igemm_v256n", "igemm_v128", "igemm_v64", "igemm_wide", "igemm_dma",
+ * "tile_order", ...): variant A/B inside one process and tests of non-default variants; PNPI_EINVAL for an unknown key */
+int pnpi_set_tuning(const char* key, int value);
 int pnpi_op_gemm(pnpi_ctx* ctx, const void* a_f16, int lda, const void* w_f16, int ldw, int M, int N, int K, float alpha,
                  const float* bias, const void* residual_f16, void* out_f16, int ldo, int vt_col0, void* outT,
                  int vt_ld, int vt_f32, int rows_per_batch, int force_cfg, int force_split);

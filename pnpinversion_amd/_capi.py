@@ -39,10 +39,11 @@ class CtrlDesc(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("unet_sample_forwards", C.c_uint64), ("unet_calls", C.c_uint64), ("vae_encodes", C.c_uint64),
-                ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double)]
+                ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double),
+                ("text_kv_rows", C.c_uint64), ("unet_sample_forwards_cached_kv", C.c_uint64)]
 
 
-KC_NAMES = ["igemm128", "igemm64", "igemm64_splitk", "attn_flash", "attn_cross_edit", "groupnorm", "layernorm", "geglu", "softmax"]
+KC_NAMES = ["igemm128", "igemm64", "igemm64_splitk", "attn_flash", "attn_cross_edit", "groupnorm", "layernorm", "geglu", "softmax", "igemm_wide"]
 
 
 class KernelStats(C.Structure):
@@ -68,6 +69,7 @@ SYMBOLS = {
     "pnpi_profile_begin": (_i, [_vp]),
     "pnpi_profile_end": (_i, [_vp, C.POINTER(KernelStats)]),
     "pnpi_unet_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(CtrlDesc), _i, _vp]),
+    "pnpi_text_kv_precompute": (_i, [_vp, _vp, _i]),
     "pnpi_local_blend": (_i, [_vp, _vp, _i, _i]),
     "pnpi_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pnpi_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -84,6 +86,8 @@ SYMBOLS = {
     "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _i, _f, _vp]),
     "pnpi_direct_edit": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CtrlDesc), _i, _i, _ip, _f, _fp, _vp, _vp]),
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
+    "pnpi_op_conv_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _ip]),
+    "pnpi_set_tuning": (_i, [C.c_char_p, _i]),
     "pnpi_op_gemm": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "pnpi_op_gemm_geglu": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
     "pnpi_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),

@@ -5,7 +5,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
+
 #include "model.h"
+
+static int g_text_kv = 1;      // tuning "text_kv" = 0: project the text context inside every forward, as the reference does (A/B)
+static int g_temb_cache = 1;   // tuning "temb_cache" = 0: three GEMVs per forward
 
 // ---------------------------------------------------------------------------------------------------- error helpers
 // explicit status + message
@@ -466,10 +471,13 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   if (!c->dry) PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)C * 2.0, launch_layernorm(hs1, M, C, 1e-5f, t.ln2.g, t.ln2.b, n2, c->st));
   half_t* q2 = talloc(c, (size_t)M * hd);
   CK(op_gemm(c, n2, C, M, C, t.w_q2, C, hd, nullptr, nullptr, 0, q2, hd, 1.f, nullptr, 2.0 * M * (double)C * C));
-  half_t* k2 = talloc(c, (size_t)B * T * hd);
   const int ldv2 = round_up_i(T, 8);
-  half_t* vt2 = talloc(c, (size_t)B * hd * ldv2);
-  {
+  half_t *k2, *vt2;
+  if (c->tkv.use) {     // projected once per loop by text_kv_precompute
+    k2 = c->tkv.k[block_index]; vt2 = c->tkv.vt[block_index];
+  } else {
+    k2 = talloc(c, (size_t)B * T * hd);
+    vt2 = talloc(c, (size_t)B * hd * ldv2);
     VtOut v; v.outT = vt2; v.col0 = hd; v.ld = ldv2; v.f32 = 0; v.rpb = T;
     CK(op_gemm(c, ctx16, X, B * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v, 2.0 * B * T * 2.0 * C * X));
   }
@@ -532,13 +540,35 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
   const int B = rows;
   const float eps = 1e-5f;
   half_t* x0 = palloc(c, (size_t)B * S * S * 8);
-  half_t* ctx16 = palloc(c, (size_t)B * g.ctx_len * g.cross_dim);
+  half_t* ctx16 = nullptr;
+  if (c->tkv.use && !c->dry) {
+    if (c->tkv.rows != B) return fail(c, PNPI_ESTATE, "text K/V cache holds a different row count than this forward");
+  } else {
+    ctx16 = palloc(c, (size_t)B * g.ctx_len * g.cross_dim);
+  }
   if (!c->dry) {
     CK(launch_nchw_f32_to_nhwc_f16(latents, B, g.in_channels, S * S, 8, x0, c->st));
-    CK(launch_f32_to_f16(context, (size_t)B * g.ctx_len * g.cross_dim, ctx16, c->st));
-    CK(launch_gemv(c->temb_table + (size_t)t * C0, C0, u.t1.w, TE, u.t1.b, nullptr, 0, c->temb_h, c->st));
-    CK(launch_gemv(c->temb_h, TE, u.t2.w, TE, u.t2.b, nullptr, 1, c->temb_emb, c->st));
-    CK(launch_gemv(c->temb_emb, TE, u.temb_w, u.temb_total, u.temb_b, u.conv1_b, 1, c->bias_eff, c->st));
+    if (ctx16) {
+      if (!context) return fail(c, PNPI_EINVAL, "context is NULL and no text K/V cache is active");
+      CK(launch_f32_to_f16(context, (size_t)B * g.ctx_len * g.cross_dim, ctx16, c->st));
+    }
+    // conv1 bias + time embedding of every ResNet for this timestep (TimestepEmbedding + the 22 time_emb_proj linears as three
+    // GEMVs): a function of t and the weights only -> computed on the first forward at t, then read from the table
+    if (c->bias_tab && g_temb_cache) {
+      float* row = c->bias_tab + (size_t)t * u.temb_total;
+      if (!c->bias_valid[t]) {
+        CK(launch_gemv(c->temb_table + (size_t)t * C0, C0, u.t1.w, TE, u.t1.b, nullptr, 0, c->temb_h, c->st));
+        CK(launch_gemv(c->temb_h, TE, u.t2.w, TE, u.t2.b, nullptr, 1, c->temb_emb, c->st));
+        CK(launch_gemv(c->temb_emb, TE, u.temb_w, u.temb_total, u.temb_b, u.conv1_b, 1, row, c->st));
+        c->bias_valid[t] = 1;
+      }
+      c->bias_eff = row;
+    } else {
+      CK(launch_gemv(c->temb_table + (size_t)t * C0, C0, u.t1.w, TE, u.t1.b, nullptr, 0, c->temb_h, c->st));
+      CK(launch_gemv(c->temb_h, TE, u.t2.w, TE, u.t2.b, nullptr, 1, c->temb_emb, c->st));
+      CK(launch_gemv(c->temb_emb, TE, u.temb_w, u.temb_total, u.temb_b, u.conv1_b, 1, c->bias_scratch, c->st));
+      c->bias_eff = c->bias_scratch;
+    }
   }
   struct Act { half_t* p; int C, H; Stats s; };
   std::vector<Act> skips;
@@ -615,6 +645,7 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
   }
   c->ctr.unet_calls += c->dry ? 0 : 1;
   c->ctr.unet_sample_forwards += c->dry ? 0 : rows;
+  c->ctr.unet_sample_forwards_cached_kv += (c->dry || !c->tkv.use) ? 0 : rows;
   if (c->persist.overflow || c->temp.overflow) return fail(c, PNPI_ENOMEM, "workspace overflow");
   return 0;
 }
@@ -723,6 +754,52 @@ static int vae_decode_fwd(pnpi_ctx* c, const half_t* z, int B, int H, int W, flo
     VtOut vv; vv.outT = out_nchw; vv.col0 = 0; vv.ld = H * W; vv.f32 = 1; vv.rpb = H * W;
     CK(op_conv(c, gno, ch, nullptr, 0, B, H, W, v.d_conv_out, 1, 1, 0, v.d_conv_out.b, nullptr, nullptr, H, W, -1, &vv));
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- text K / V cache
+static void for_each_transformer(pnpi_ctx* c, const std::function<void(const TransformerW&, int)>& fn) {
+  UNetW& u = c->unet;
+  int idx = 0;
+  for (auto& blk : u.down_attn) for (auto& t : blk) fn(t, idx++);
+  fn(u.mid_attn, idx++);
+  for (auto& blk : u.up_attn) for (auto& t : blk) fn(t, idx++);
+}
+static size_t text_kv_bytes(pnpi_ctx* c, int rows) {
+  const int T = c->cfg.ctx_len, ldv = round_up_i(T, 8);
+  size_t total = 0;
+  for_each_transformer(c, [&](const TransformerW& t, int) {
+    const size_t hd = (size_t)t.heads * t.Dp;
+    total += align_up((size_t)rows * T * hd * sizeof(half_t), 256) + align_up((size_t)rows * hd * ldv * sizeof(half_t), 256);
+  });
+  return total + 4096;
+}
+// K = context W_k^T, V^T = (context W_v^T)^T for the 16 cross-attention layers, `rows` context rows (fp32 [rows][T][X] on the device)
+static int text_kv_precompute(pnpi_ctx* c, const float* context, int rows) {
+  const pnpi_model_config& g = c->cfg;
+  TextKV& kv = c->tkv;
+  kv.rows = 0; kv.use = false;
+  if (rows <= 0 || rows > c->max_rows) return fail(c, PNPI_EINVAL, "text K/V precompute: rows out of range (max_unet_rows)");
+  if (text_kv_bytes(c, rows) > kv.cap) return fail(c, PNPI_ENOMEM, "text K/V cache arena too small");
+  const int T = g.ctx_len, X = g.cross_dim, ldv = round_up_i(T, 8);
+  c->persist.reset(); c->temp.reset();
+  half_t* ctx16 = palloc(c, (size_t)rows * T * X);
+  CK(launch_f32_to_f16(context, (size_t)rows * T * X, ctx16, c->st));
+  kv.k.clear(); kv.vt.clear();
+  size_t off = 0;
+  int rc = 0;
+  for_each_transformer(c, [&](const TransformerW& t, int) {
+    if (rc) return;
+    const int hd = t.heads * t.Dp;
+    half_t* k2 = (half_t*)(kv.base + off); off += align_up((size_t)rows * T * hd * sizeof(half_t), 256);
+    half_t* vt2 = (half_t*)(kv.base + off); off += align_up((size_t)rows * hd * ldv * sizeof(half_t), 256);
+    kv.k.push_back(k2); kv.vt.push_back(vt2);
+    VtOut v; v.outT = vt2; v.col0 = hd; v.ld = ldv; v.f32 = 0; v.rpb = T;
+    rc = op_gemm(c, ctx16, X, rows * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v, 2.0 * rows * T * 2.0 * t.C * X);
+  });
+  if (rc) return fail_launch(c, rc, "text K/V projection");
+  kv.rows = rows;
+  c->ctr.text_kv_rows += rows;
   return 0;
 }
 
@@ -919,13 +996,21 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
   build_model(c);
   // small persistent buffers
   const int C0 = g.block_out_channels[0], TE = 4 * C0;
-  c->splitk_bytes = (size_t)96 << 20;
+  c->splitk_bytes = ((size_t)96 << 20) + (size_t)(max_unet_rows > 12 ? max_unet_rows - 12 : 0) * ((size_t)8 << 20);   // grows with the rows per launch
   CKH(hipMalloc((void**)&c->splitk_ws, c->splitk_bytes));
   size_t gnp = (size_t)(max_unet_rows > max_vae_images ? max_unet_rows : max_vae_images) * (128 * 64 * 2 + 4096 * 2) * sizeof(float);
   CKH(hipMalloc((void**)&c->gn_partial, gnp));
   CKH(hipMalloc((void**)&c->temb_h, TE * sizeof(float)));
   CKH(hipMalloc((void**)&c->temb_emb, TE * sizeof(float)));
-  CKH(hipMalloc((void**)&c->bias_eff, (size_t)c->unet.temb_total * sizeof(float)));
+  CKH(hipMalloc((void**)&c->bias_scratch, (size_t)c->unet.temb_total * sizeof(float)));
+  c->bias_eff = c->bias_scratch;
+  if (max_unet_rows > 0) {
+    // per-timestep (conv1 bias + time embedding) table: [n_train][temb_total] fp32 (81 MB for SD-1.x), rows filled on first use
+    CKH(hipMalloc((void**)&c->bias_tab, (size_t)g.n_train_timesteps * c->unet.temb_total * sizeof(float)));
+    c->bias_valid.assign(g.n_train_timesteps, 0);
+    c->tkv.cap = text_kv_bytes(c, max_unet_rows);
+    CKH(hipMalloc((void**)&c->tkv.base, c->tkv.cap));
+  }
   // sinusoidal timestep table, get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0), fp64 -> fp32
   // (my_diffusers/models/embeddings.py:21-60)
   {
@@ -1004,13 +1089,19 @@ void pnpi_destroy(pnpi_ctx* c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->st);
   void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial,
-                  c->temb_table, c->temb_h, c->temb_emb, c->bias_eff, c->rows_ident};
+                  c->temb_table, c->temb_h, c->temb_emb, c->bias_scratch, c->bias_tab, c->tkv.base, c->rows_ident};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
 }
 
+static void invalidate_derived(pnpi_ctx* c) {     // caches of functions of the weights
+  std::fill(c->bias_valid.begin(), c->bias_valid.end(), 0);
+  c->tkv.rows = 0; c->tkv.use = false;
+}
+
 int pnpi_load_weights(pnpi_ctx* c, const pnpi_named_tensor* ts, int n) {
   if (!c || !ts) return PNPI_EINVAL;
+  invalidate_derived(c);
   for (int i = 0; i < n; ++i) {
     const pnpi_named_tensor& t = ts[i];
     std::string name = t.name;
@@ -1061,6 +1152,7 @@ int pnpi_weight_arena(pnpi_ctx* c, void** ptr, size_t* bytes) {
 }
 
 int pnpi_mark_all_loaded(pnpi_ctx* c) {
+  invalidate_derived(c);            // the arena was just overwritten by the broadcast
   for (auto& kv : c->slots) kv.second.loaded = true;
   return 0;
 }
@@ -1124,10 +1216,19 @@ static int check_clip_ready(pnpi_ctx* c) {
   return 0;
 }
 
+int pnpi_text_kv_precompute(pnpi_ctx* c, const float* context, int rows) {
+  if (!c || !context) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  return text_kv_precompute(c, context, rows);
+}
+
 int pnpi_unet_forward(pnpi_ctx* c, const float* latents, int rows, int rows_per_image, int t, const float* context,
                       const pnpi_ctrl_desc* ctrl_host, int cur_step, float* eps_out) {
-  if (!c || !latents || !context || !eps_out) return PNPI_EINVAL;
+  if (!c || !latents || !eps_out) return PNPI_EINVAL;
   CKP(check_ready(c));
+  if (!context && c->tkv.rows != rows) return fail(c, PNPI_ESTATE, "context is NULL: call pnpi_text_kv_precompute for this row count first");
+  struct UseKV { pnpi_ctx* c; ~UseKV() { c->tkv.use = false; } } guard{c};
+  c->tkv.use = context == nullptr;
   bool use_ctrl = false;
   if (ctrl_host) {
     if (rows_per_image != 4 || rows % 4) return fail(c, PNPI_EINVAL, "controllers need rows_per_image == 4");
@@ -1299,6 +1400,19 @@ int pnpi_text_encode(pnpi_ctx* c, const int32_t* input_ids, int n, float* hidden
 }
 
 // ---- level 2 loops. Scratch for the loops lives at the top of the controller arena (after the controller tables).
+// The loops' text context is constant over their steps: project K / V once, then every forward of the loop reads the cache.
+struct LoopKV {
+  pnpi_ctx* c;
+  explicit LoopKV(pnpi_ctx* c_) : c(c_) {}
+  int begin(const float* context, int rows) {
+    if (!g_text_kv) return 0;
+    int r = text_kv_precompute(c, context, rows);
+    if (r) return r;
+    c->tkv.use = true;
+    return 0;
+  }
+  ~LoopKV() { c->tkv.use = false; }
+};
 int pnpi_ddim_invert(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_cond, int nsteps, const int* ts, float* all) {
   if (!c || !z0 || !ctx_cond || !ts || !all || nsteps <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
@@ -1308,6 +1422,8 @@ int pnpi_ddim_invert(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_co
   CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
   float* eps = misc_f(c, (size_t)nimg * E);
   CKH(hipMemcpyAsync(all, z0, (size_t)nimg * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  LoopKV kv(c);
+  CKP(kv.begin(ctx_cond, nimg));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[nsteps - i - 1];
     const float* cur = all + (size_t)i * nimg * E;
@@ -1344,6 +1460,8 @@ int pnpi_ddim_invert_cfg(pnpi_ctx* c, const float* z0, int nimg, const float* ct
     CKH(hipMemcpyAsync(ctx2 + (size_t)(2 * i + 1) * CE, ctx_cond + (size_t)i * CE, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
   }
   CKH(hipMemcpyAsync(all, z0, (size_t)nimg * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  LoopKV kv(c);
+  CKP(kv.begin(ctx2, rows));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[nsteps - i - 1];
     const float* cur = all + (size_t)i * nimg * E;
@@ -1381,6 +1499,8 @@ int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const flo
   CKP(upload_ints(c, expand, &d_expand));
   CKP(upload_ints(c, inmap, &d_inmap));
   CK(launch_gather_rows_f32(lat_all + (size_t)nsteps * nimg * E, d_expand, nimg * 2, E, cur, c->st));
+  LoopKV kv(c);
+  CKP(kv.begin(context4, rows));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
     CK(launch_gather_rows_f32(cur, d_inmap, rows, E, in, c->st));
@@ -1417,6 +1537,8 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   CKP(upload_ints(c, inmap, &d_inmap));
   CK(launch_gather_rows_f32(x_T, d_expand, nimg * 2, E, lat, c->st));
   if (prox && !(quantile > 0.f)) CK(launch_fill_f32(thr, nimg, -quantile, c->st));   // negative quantile = fixed threshold (:43-44)
+  LoopKV kv(c);
+  CKP(kv.begin(context4, rows));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
     CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
@@ -1467,6 +1589,8 @@ int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* c
   if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
   CK(launch_gather_rows_f32(lat_all + (size_t)nsteps * nimg * E, d_expand, NI * 2, E, lat, c->st));
   CK(launch_gather_rows_f32(context4, d_ctxmap, rows, CE, ctxrep, c->st));
+  LoopKV kv(c);
+  CKP(kv.begin(ctxrep, rows));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
     CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
@@ -1497,6 +1621,29 @@ int pnpi_op_conv(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, in
   p.bias = bias; p.res = (const half_t*)res; p.ldres = N; p.out = (half_t*)out; p.ldo = N;
   CK(launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, force_cfg, force_split));
   return 0;
+}
+/* conv + the per-(m-tile, channel) GroupNorm partial sums its epilogue produces (the statistics fusion of resnet_fwd): stats_out
+ * [ceil(M / tile_rows)][N][2] fp32 = (sum, sum of squares) of the stored fp16 values; *tile_rows_out = rows per m-tile, 0 when the
+ * launch configuration produced no statistics (split-K, non-DMA shapes). */
+int pnpi_op_conv_stats(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int H, int W, int ksize, int stride, int pad,
+                       int ups, int Ho, int Wo, const void* w, const float* bias, const void* res, int N, void* out, int force_cfg,
+                       int force_split, float* stats_out, int* tile_rows_out) {
+  if (!c || !stats_out || !tile_rows_out) return PNPI_EINVAL;
+  GemmP p; gemm_defaults(p);
+  p.x1 = (const half_t*)x1; p.x2 = (const half_t*)x2; p.C1 = C1; p.C2 = C2; p.ldx1 = C1; p.ldx2 = C2;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups;
+  p.K = ksize * ksize * (C1 + C2); p.w = (const half_t*)w; p.ldw = p.K; p.M = B * Ho * Wo; p.N = N;
+  p.bias = bias; p.res = (const half_t*)res; p.ldres = N; p.out = (half_t*)out; p.ldo = N; p.stats = stats_out;
+  CK(launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, force_cfg, force_split, nullptr, tile_rows_out));
+  return 0;
+}
+/* process-wide kernel tuning knobs (tile-variant A/B inside one process, tests of non-default variants) */
+int pnpi_set_tuning(const char* key, int value) {
+  if (!key) return PNPI_EINVAL;
+  if (!strcmp(key, "text_kv")) { g_text_kv = value; return 0; }
+  if (!strcmp(key, "temb_cache")) { g_temb_cache = value; return 0; }
+  if (!strcmp(key, "gn_inline_rows")) { norm_set_tuning_gn_inline_rows(value); return 0; }
+  return igemm_set_tuning(key, value) == 0 ? 0 : PNPI_EINVAL;
 }
 int pnpi_op_gemm(pnpi_ctx* c, const void* a, int lda, const void* w, int ldw, int M, int N, int K, float alpha, const float* bias,
                  const void* res, void* out, int ldo, int vt_col0, void* outT, int vt_ld, int vt_f32, int rpb, int force_cfg,

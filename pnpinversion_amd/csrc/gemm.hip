@@ -10,6 +10,7 @@
 // global -> registers -> LDS staging (the conv gather needs per-lane predication, which LDS-DMA cannot do), LDS rows
 // padded by 16 B so that ds_read_b128 fragment reads are bank-conflict free (stride 144 B = 36 banks).
 #include <stdlib.h>
+#include <string.h>
 
 #include "ops.h"
 
@@ -313,17 +314,43 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+static int g_tile_order = -1;   // PNPI_TILE_ORDER: force 0 / 1 (ablation)
 
 // ABL: 0 = product kernel; 1 = DMA only (no fragment reads / MFMA); 2 = compute only (no DMA); 3 = activation operand loaded for
 // the first filter tap only -- bottleneck ablations for tools/ (1-3 produce garbage).
-template <int BM, int BN, int BKT, int NST, int ABL = 0>
-__global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
+//
+// Tile geometry: WGM x 2 wavefronts (NT = 128 * WGM threads); a wave owns (BM / WGM) x (BN / 2) of the block tile as 32x32 MFMA
+// tiles.  Instantiated shapes (BM x BN, wave tile): 64x64 (32x32), 128x128 (64x64), 128x256 (64x128), 128x320 (64x160: 20
+// MFMAs per 32-deep k-chunk and barrier, 91 FLOP per operand byte -- the N = 320 / 640 / 1280 layers tile exactly), 256x128.
+template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0>
+struct IgemmGeom {
+  static constexpr int NW = 2 * WGM, NT = 64 * NW;
+  static constexpr int WM = BM / WGM, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  static constexpr int RPI = 1024 / (BKT * 2);                 // tile rows per 1-KiB DMA instruction (8 or 16)
+  static constexpr int AV = BM / RPI / NW, WV = BN / RPI / NW;  // DMA instructions per wave per chunk and operand
+  static constexpr int ROWB = BKT * 2;                          // bytes per tile row
+  static constexpr int STAGE = (BM + BN) * ROWB;                // bytes
+  static constexpr int RING = NST * STAGE;
+  // LDS epilogue: the output tile is staged as [rows][BN + 8] halfs in the idle ring, EPASS passes of EROWS rows (one row of
+  // waves per pass when the whole tile does not fit), then written as full rows; G row groups of VPR 16-byte vectors.
+  static constexpr int OLD = BN + 8, VPR = BN / 8, G = NT / VPR;
+  static constexpr int STATS_B = G * BN * 2 * 4;
+  static constexpr int EPASS = (BM * OLD * 2 + STATS_B <= RING) ? 1 : WGM;
+  static constexpr int EROWS = BM / EPASS;
+  static constexpr int EPI = EROWS * OLD * 2 + STATS_B;
+  static constexpr int LDS = RING > EPI ? RING : EPI;
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "DMA instructions must divide evenly over the waves");
+  static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % 64 == 0, "wave tile");
+};
+
+template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0>
+__global__ void __launch_bounds__(128 * WGM, (IgemmGeom<BM, BN, BKT, NST, WGM>::LDS * 2 <= 160 * 1024 && BN <= 320) ? (2 * 2 * WGM / 4) : (2 * WGM / 4))
+igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   static_assert(BKT == 64 || BKT == 32, "BKT");
-  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
-  constexpr int RPI = 1024 / (BKT * 2);                // tile rows per 1-KiB DMA instruction (8 or 16)
-  constexpr int AV = BM / RPI / 4, WV = BN / RPI / 4;  // DMA instructions per wave per chunk and operand
-  constexpr int ROWB = BKT * 2;                        // bytes per tile row
-  constexpr int STAGE = (BM + BN) * ROWB;              // bytes
+  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM>;
+  constexpr int NT = GEO::NT, NW = GEO::NW;
+  constexpr int WM = GEO::WM, WN = GEO::WN, MI = GEO::MI, NI = GEO::NI;
+  constexpr int AV = GEO::AV, WV = GEO::WV, ROWB = GEO::ROWB, STAGE = GEO::STAGE;
   constexpr int T32 = 32 * ROWB;                       // bytes per 32-row MFMA tile
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
 
@@ -478,22 +505,34 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma
       else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
       __builtin_amdgcn_s_barrier();
-      if (issued < total) { if (ABL != 2) issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
-      if (ABL == 1) { rd = rd + 1 == NST ? 0 : rd + 1; continue; }
+      if (ABL == 1) {
+        if (issued < total) { issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
+        rd = rd + 1 == NST ? 0 : rd + 1;
+        continue;
+      }
       const char* sA = smem_raw + rd * STAGE + (wm0 >> 5) * T32 + lane_row_off;
       const char* sW = smem_raw + rd * STAGE + BM * ROWB + (wn0 >> 5) * T32 + lane_row_off;
-#pragma unroll
-      for (int kk = 0; kk < BKT / 16; ++kk) {
+      // Software pipeline inside the chunk: the fragments of k-step kk+1 are read while the MFMAs of k-step kk run, and the
+      // first k-step's reads are issued BEFORE the next chunk's DMA instructions (their issue slots -- ~100 cycles each -- then
+      // overlap the LDS latency instead of preceding it).  One exposed LDS round trip per chunk instead of one per k-step.
+      constexpr int KS = BKT / 16;
+      half8 wf[2][NI], af[2][MI];
+      auto frag_load = [&](int slot, int kk) {
         const int ko = ((kk * 2 + hk) ^ xk) * 16;
-        half8 wf[NI], af[MI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const half8*>(sW + ni * T32 + ko);
+        for (int mi = 0; mi < MI; ++mi) af[slot][mi] = *reinterpret_cast<const half8*>(sA + mi * T32 + ko);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8*>(sA + mi * T32 + ko);
+        for (int ni = 0; ni < NI; ++ni) wf[slot][ni] = *reinterpret_cast<const half8*>(sW + ni * T32 + ko);
+      };
+      frag_load(0, 0);
+      if (issued < total) { if (ABL != 2) issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        if (kk + 1 < KS) frag_load((kk + 1) & 1, kk + 1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(wf[ni], af[mi], acc[mi][ni]);
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(wf[kk & 1][ni], af[kk & 1][mi], acc[mi][ni]);
       }
       rd = rd + 1 == NST ? 0 : rd + 1;
     }
@@ -502,106 +541,113 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma
   if (p.epi_lds && p.splitk <= 1) {
     // Coalesced epilogue: the output tile is assembled in LDS (the ring is idle now) and written as full rows, 16 bytes per
     // lane.  The residual tile is staged the same way, so out = fp16(alpha*acc + bias + residual) with a single rounding.
-    constexpr int OLD = BN + 8;                         // halfs per staged row
-    constexpr int VPR = BN / 8;                         // 16-byte vectors per row
+    // EPASS passes of EROWS rows (pass e = the waves of wave-row e when the tile is staged in parts).  Store loop: thread t owns
+    // the fixed 16-byte vector v = t % VPR of row group g = t / VPR and walks rows g, g + G, ...: per-channel sums for the
+    // GroupNorm that consumes this tensor fall out of it (fp32 sums of the rounded fp16 values the consumer will read), and every
+    // partial is combined in a FIXED order (rows ascending per thread, then groups ascending): bit-reproducible statistics.
+    constexpr int OLD = GEO::OLD, VPR = GEO::VPR, G = GEO::G, EPASS = GEO::EPASS, EROWS = GEO::EROWS;
     half_t* sOut = reinterpret_cast<half_t*>(smem_raw);
+    const int sv = tid % VPR, sg = tid / VPR;
+    const bool s_active = sg < G;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.res) {
-      for (int idx = tid; idx < BM * VPR; idx += 256) {
-        const int r = idx / VPR, v = idx - r * VPR;
-        const int m = m0 + r, n = n0 + v * 8;
-        half8 val = (m < p.M && n < p.N) ? ldg_half8(p.res + (size_t)m * p.ldres + n) : zero_half8();
-        *reinterpret_cast<half8*>(sOut + r * OLD + v * 8) = val;
+#pragma unroll
+    for (int e = 0; e < EPASS; ++e) {
+      const int r0 = e * EROWS;                         // first tile row of this pass
+      if (p.res) {
+        if (s_active)
+          for (int r = sg; r < EROWS; r += G) {
+            const int m = m0 + r0 + r, n = n0 + sv * 8;
+            half8 val = (m < p.M && n < p.N) ? ldg_half8(p.res + (size_t)m * p.ldres + n) : zero_half8();
+            *reinterpret_cast<half8*>(sOut + r * OLD + sv * 8) = val;
+          }
+        __syncthreads();
+      }
+      if (EPASS == 1 || (wave >> 1) == e) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int ml = wm0 - r0 + mi * 32 + (lane & 31);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+              const int n = n0 + nl;
+              half4* slot = reinterpret_cast<half4*>(sOut + ml * OLD + nl);
+              float o[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                o[j] = acc[mi][ni][4 * g + j] * p.alpha;
+                if (p.bias && n + j < p.N) o[j] += p.bias[n + j];
+              }
+              if (p.res) {
+                half4 r4 = *slot;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+              }
+              half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+              *slot = h4;
+            }
+          }
+        }
       }
       __syncthreads();
-    }
+      if (!p.geglu) {
+        if (s_active) {
+          const int n = n0 + sv * 8;
+          for (int r = sg; r < EROWS; r += G) {
+            const int m = m0 + r0 + r;
+            if (m < p.M && n < p.N) {
+              const half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + sv * 8);
+              *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = val;
+              if (p.stats) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int ml = wm0 + mi * 32 + (lane & 31);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
-          const int n = n0 + nl;
-          half4* slot = reinterpret_cast<half4*>(sOut + ml * OLD + nl);
-          float o[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            o[j] = acc[mi][ni][4 * g + j] * p.alpha;
-            if (p.bias && n + j < p.N) o[j] += p.bias[n + j];
+                for (int j = 0; j < 8; ++j) { float f = (float)val[j]; cs[j] += f; cq[j] += f * f; }
+              }
+            }
           }
-          if (p.res) {
-            half4 r4 = *slot;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
-          }
-          half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-          *slot = h4;
         }
-      }
-    }
-    __syncthreads();
-    if (!p.geglu) {
-      // thread t owns the fixed 8-channel vector v = t % VPR and walks rows: per-channel sums for the GroupNorm that
-      // consumes this tensor fall out of the store loop (fp32 sums of the rounded fp16 values the consumer will read)
-      float cs[8], cq[8];
+      } else {
+        // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
+        constexpr int VPO = BN / 16;
+        for (int idx = tid; idx < EROWS * VPO; idx += NT) {
+          const int r = idx / VPO, v = idx - r * VPO;
+          const int m = m0 + r0 + r;
+          const int xc = (v >> 2) * 64 + (v & 3) * 8;     // local column of the x vector; its gate sits 32 columns further
+          const int no = (n0 >> 1) + v * 8;
+          if (m < p.M && no < (p.N >> 1)) {
+            half8 x = *reinterpret_cast<const half8*>(sOut + r * OLD + xc);
+            half8 gt = *reinterpret_cast<const half8*>(sOut + r * OLD + xc + 32);
+            half8 o8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
-      for (int idx = tid; idx < BM * VPR; idx += 256) {
-        const int r = idx / VPR, v = idx - r * VPR;
-        const int m = m0 + r, n = n0 + v * 8;
-        if (m < p.M && n < p.N) {
-          const half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + v * 8);
-          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = val;
-          if (p.stats) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = (float)val[j]; cs[j] += f; cq[j] += f * f; }
+            for (int j = 0; j < 8; ++j) o8[j] = (half_t)((float)x[j] * gelu_f((float)gt[j]));
+            *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + no) = o8;
           }
         }
       }
-      if (p.stats) {
-        // lanes sharing a vector index are VPR apart: fold them inside the wave, then across the 4 waves through LDS
-        float* sSt = reinterpret_cast<float*>(sOut + BM * OLD);       // [4][BN][2]
+      if (e + 1 < EPASS) __syncthreads();               // the next pass overwrites the staging rows
+    }
+    if (p.stats && !p.geglu) {
+      float* sSt = reinterpret_cast<float*>(sOut + EROWS * OLD);       // [G][BN][2]
+      if (s_active) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#pragma unroll
-          for (int off = VPR; off < 64; off <<= 1) { cs[j] += __shfl_xor(cs[j], off, 64); cq[j] += __shfl_xor(cq[j], off, 64); }
-        }
-        const int lane_ = tid & 63, wv = tid >> 6;
-        if (lane_ < VPR) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            sSt[(wv * BN + lane_ * 8 + j) * 2 + 0] = cs[j];
-            sSt[(wv * BN + lane_ * 8 + j) * 2 + 1] = cq[j];
-          }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
-          float s = 0.f, q = 0.f;
-#pragma unroll
-          for (int w4 = 0; w4 < 4; ++w4) { s += sSt[(w4 * BN + tid) * 2]; q += sSt[(w4 * BN + tid) * 2 + 1]; }
-          float* dst = p.stats + ((size_t)bx * p.N + n0 + tid) * 2;
-          dst[0] = s;
-          dst[1] = q;
+          sSt[(sg * BN + sv * 8 + j) * 2 + 0] = cs[j];
+          sSt[(sg * BN + sv * 8 + j) * 2 + 1] = cq[j];
         }
       }
-    } else {
-      // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
-      constexpr int VPO = BN / 16;
-      for (int idx = tid; idx < BM * VPO; idx += 256) {
-        const int r = idx / VPO, v = idx - r * VPO;
-        const int m = m0 + r;
-        const int xc = (v >> 2) * 64 + (v & 3) * 8;     // local column of the x vector; its gate sits 32 columns further
-        const int no = (n0 >> 1) + v * 8;
-        if (m < p.M && no < (p.N >> 1)) {
-          half8 x = *reinterpret_cast<const half8*>(sOut + r * OLD + xc);
-          half8 gt = *reinterpret_cast<const half8*>(sOut + r * OLD + xc + 32);
-          half8 o8;
+      __syncthreads();
+      for (int c = tid; c < BN; c += NT) {
+        if (n0 + c < p.N) {
+          float s = 0.f, q = 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o8[j] = (half_t)((float)x[j] * gelu_f((float)gt[j]));
-          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + no) = o8;
+          for (int g = 0; g < G; ++g) { s += sSt[(g * BN + c) * 2]; q += sSt[(g * BN + c) * 2 + 1]; }
+          float* dst = p.stats + ((size_t)bx * p.N + n0 + c) * 2;
+          dst[0] = s;
+          dst[1] = q;
         }
       }
     }
@@ -620,9 +666,12 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma
         if (p.splitk > 1) {
           if (m < p.M) {
             float* dst = p.slab + ((size_t)bz * p.M + m) * p.N + nb;
+            if (nb + 3 < p.N) *reinterpret_cast<floatx4*>(dst) = floatx4{v[0], v[1], v[2], v[3]};
+            else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (nb + j < p.N) dst[j] = v[j];
+              for (int j = 0; j < 4; ++j)
+                if (nb + j < p.N) dst[j] = v[j];
+            }
           }
         } else {
           epilogue_store4(p, m, nb, v);
@@ -632,9 +681,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 128) ? 2 : 1) igemm_dma
   }
 }
 
-static int g_tile_order = -1;   // PNPI_TILE_ORDER: force 0 / 1 (ablation)
-template <int BM, int BN, int BKT, int NST, int ABL = 0>
+template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0>
 static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t* zero_page) {
+  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM>;
   GemmP p = p_in;
   p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
   {
@@ -644,13 +693,12 @@ static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t
   }
   const int total = (int)(grid.x * grid.y * grid.z);
   grid = dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
-  constexpr int ring = NST * (BM + BN) * BKT * 2, epi = BM * (BN + 8) * 2 + 4 * BN * 2 * 4;   // the LDS epilogue re-uses the ring
-  constexpr int lds = ring > epi ? ring : epi;
+  constexpr int lds = GEO::LDS;
   static unsigned long long attr_devs = 0;
   if (first_on_device(attr_devs)) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  igemm_dma_kernel<BM, BN, BKT, NST, ABL><<<grid, 256, lds, st>>>(p, zero_page);
+  igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL><<<grid, GEO::NT, lds, st>>>(p, zero_page);
   return 0;
 }
 
@@ -684,16 +732,29 @@ static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 *
 
 static half_t* g_zero_page = nullptr;
 static constexpr size_t ZERO_PAGE_BYTES = 128 << 10;   // >= 2 * (longest K + one chunk): out-of-range rows walk it like real rows
+static int g_wide = 1;      // PNPI_IGEMM_WIDE=0: never pick the 128x320 / 128x256 tiles (ablation)
 static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
-static int g_var128 = 2, g_var64 = 0, g_var256 = 0;
+static int g_force_cfg = -1;   // >= 0: every auto-configured launch uses this tile configuration (tests, whole-forward A/B)
+static int g_var128 = 2, g_var64 = 0, g_var256 = 0, g_var320 = 1, g_var256n = 1;
 static long g_v128_bk64_tiles = 0;   // PNPI_V128_BK64_TILES: tile count from which the 128x128 kernel switches to 128-byte rows   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
 void igemm_set_dma(int on) { g_use_dma = on; }
+// process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
+int igemm_set_tuning(const char* key, int v) {
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}};
+  for (auto& e : tab)
+    if (!strcmp(key, e.k)) { *e.p = v; return 0; }
+  return -1;
+}
 
 int igemm_init() {
   if (const char* e = getenv("PNPI_IGEMM_DMA")) g_use_dma = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V128")) g_var128 = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V64")) g_var64 = atoi(e);
   if (const char* e = getenv("PNPI_IGEMM_V256")) g_var256 = atoi(e);
+  if (const char* e = getenv("PNPI_IGEMM_V320")) g_var320 = atoi(e);
+  if (const char* e = getenv("PNPI_IGEMM_V256N")) g_var256n = atoi(e);
+  if (const char* e = getenv("PNPI_IGEMM_WIDE")) g_wide = atoi(e);
   if (const char* e = getenv("PNPI_V128_BK64_TILES")) g_v128_bk64_tiles = atol(e);
   if (const char* e = getenv("PNPI_TILE_ORDER")) g_tile_order = atoi(e);
   if (!g_zero_page) {
@@ -707,6 +768,17 @@ int igemm_init() {
   return 0;
 }
 
+// Tile configurations of the LDS-DMA kernel (cfg ids of launch_igemm's force_cfg / tools): 0 = 128x128, 1 = 64x64 (2 = the same
+// with split-K forced), 3 = 256x128 (ablation), 4 = 128x320, 5 = 128x256.
+struct TileCfg { int id, bm, bn; double rate, t_fix; int bpc; };   // rate: FLOP/s of the whole chip with every CU full; t_fix: per-tile
+static const TileCfg kTiles[] = {                                  // prologue + epilogue seconds; bpc: co-resident blocks per CU
+  {0, 128, 128, 863e12, 1.20e-6, 3},
+  {1, 64, 64, 594e12, 0.29e-6, 4},
+  {4, 128, 320, 997e12, 4.85e-6, 2},
+  {5, 128, 256, 1080e12, 3.76e-6, 2},
+};
+// experimental 8-wave tiles (cfg 6 = 256x320, cfg 7 = 256x256; 128-byte rows, two stages, one block per CU): force_cfg only
+
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used,
                  int* stats_tile_rows) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -2;
@@ -716,106 +788,119 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (p.vt_col0 > p.N) p.vt_col0 = p.N;
   const bool fast = (Cin % BK == 0) && (p.C1 % BK == 0);
   const int nchunks = (p.K + BK - 1) / BK;
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  const bool dma_ok = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0) && ((size_t)p.K * 2 + 1024 <= ZERO_PAGE_BYTES);
+  auto tiles_of = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const long t64 = tiles_of(64, 64);
   int cfg = force_cfg;
   int split = 1;
+  if (cfg < 0 && g_force_cfg >= 0) cfg = g_force_cfg == 2 ? 1 : g_force_cfg;
   if (cfg < 0) {
-    // Tile / split-K selection by a small cost model (constants fitted to per-shape timings on MI355X):
-    //   time ~ flops / (rate(tile) * busy CUs * residency factor) + split-K reduction traffic.
-    // 128x128 tiles move half the operand bytes per FLOP of 64x64 tiles (the LDS-DMA path is the limiter), but need split-K
-    // on the low-resolution layers to put work on all 256 CUs.
+    // Tile / split-K selection by a small cost model (constants fitted to per-shape timings on MI355X, tools/fit_cost_model.py):
+    //   time ~ (units on the busiest CU) x (padded FLOPs of one unit) / (per-CU rate of the tile x co-residency factor)
+    //          + split-K slab traffic + the reduce launch.
+    // Wider tiles move fewer operand bytes per FLOP through the LDS-DMA path (the limiter), but need split-K on the
+    // low-resolution layers to put work on all 256 CUs.
     double best = 1e30;
-    static const int splits[] = {1, 2, 3, 4, 6, 8, 12};
-    // constants refitted offline (tools/fit_cost_model.py) against per-shape timings of every configuration at 1, 4, 12 and 48
-    // UNet rows (tools/autotune_report.py): regret vs the per-shape best 0.3 - 2 % (was 1 - 9 %)
-    for (int tile = 0; tile < 2; ++tile) {
-      const long tiles = tile == 0 ? t128 : t64;
-      const double rate = tile == 0 ? 840e12 : 520e12;
-      const double flops = 2.0 * (double)tiles * (tile == 0 ? 128.0 * 128.0 : 64.0 * 64.0) * p.K;   // padded tiles do real work
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (const TileCfg& tc : kTiles) {
+      if (tc.id >= 4 && !(dma_ok && g_wide)) continue;     // the wide tiles exist only as LDS-DMA kernels
+      const long tiles = tiles_of(tc.bm, tc.bn);
       for (int s : splits) {
-        if (tile == 0 && s > 4) break;
         if (s > 1 && (nchunks / s < 4 || (size_t)s * p.M * p.N * sizeof(float) > ws_bytes || ws == nullptr)) continue;
         if (s > 1 && p.geglu) continue;
-        const double blocks = (double)tiles * s;
-        const double per_cu = blocks / 256.0;
-        const double busy = per_cu < 1.0 ? per_cu : 1.0;
-        // co-resident blocks cover each other's exposed loads: one block per CU runs at 0.70 of the tile's rate, two at 0.97
-        const double resid = per_cu < 1.0 ? 0.70 : (per_cu < 2.0 ? 0.70 + 0.27 * (per_cu - 1.0) : (per_cu < 3.0 ? 0.97 + 0.03 * (per_cu - 2.0) : 1.0));
-        double t = flops / (rate * busy * resid);
-        if (s > 1) t += (double)(2 * s + 1) * p.M * p.N * 4.0 / 2.5e12 + 10e-6;   // slabs written, re-read, output + the reduce launch
-        if (t < best) { best = t; cfg = tile == 0 ? 0 : (s > 1 ? 2 : 1); split = s; }
+        // constants: tools/fit_cost_model2.py on tools/autotune2.py timings of every configuration per layer shape (rms log error
+        // 0.10; the picks cost 1 % more than the per-shape best over a 12-row forward)
+        const double unit = tc.t_fix + (double)((nchunks + s - 1) / s) * (2.0 * tc.bm * tc.bn * BK) / (tc.rate / 256.0);   // padded tiles do real work
+        const long units = tiles * s;
+        const long on_busiest = (units + 255) / 256;
+        const double per_cu = (double)units / 256.0;
+        // co-resident blocks cover each other's exposed loads: a lone block on a CU runs below the tile's full rate
+        const double fill = per_cu >= tc.bpc ? 1.0 : (per_cu <= 1.0 ? 0.0 : (per_cu - 1.0) / (tc.bpc - 1.0));
+        const double resid = 0.835 + 0.165 * fill;
+        double t = (double)on_busiest * unit / resid;
+        if (s > 1) t += (double)(2 * s + 1) * p.M * p.N * 4.0 / 8.77e12 + 4.94e-6;   // slabs written, re-read, output + the reduce launch
+        if (t < best) { best = t; cfg = tc.id; split = s; }
       }
     }
   } else if (cfg == 2) {
+    cfg = 1;
     split = force_split > 0 ? force_split : (int)((512 + t64 - 1) / t64);
     if (split > 16) split = 16;
     if (split > nchunks) split = nchunks;
     while (split > 1 && nchunks / split < 4) --split;
-    size_t need = (size_t)split * p.M * p.N * sizeof(float);
-    if (split > 1 && (ws == nullptr || need > ws_bytes)) split = 1;
-  } else if (cfg == 0 && force_split > 1) {
+  } else if (force_split > 1) {
     split = force_split;
   }
+  if (cfg >= 3 && !dma_ok) cfg = 0;                                 // 256x128 / 128x320 / 128x256 exist only as LDS-DMA kernels
   // whatever chose the split (cost model or a caller-forced value): the slabs must fit the workspace and each split needs work
   if (split > 1) {
     if (split > nchunks) split = nchunks;
-    if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu) split = 1;
+    if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu || cfg == 3) split = 1;
   }
-  if (cfg_used) *cfg_used = split > 1 ? 2 : ((cfg == 0 || cfg == 3) ? 0 : 1);
+  if (cfg_used) *cfg_used = split > 1 ? 2 : (cfg >= 4 ? 9 : (cfg == 1 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   p.epi_lds = (p.vt_col0 >= p.N) && (p.N % 8 == 0) && (p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
-  if (p.geglu && !(p.epi_lds && fast && g_use_dma && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
-  const bool dma_ok = fast && g_use_dma && (p.K % BK == 0) && (p.ldw % 8 == 0) && ((size_t)p.K * 2 + 1024 <= ZERO_PAGE_BYTES);
+  if (p.geglu && !(p.epi_lds && dma_ok && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
-  if (cfg == 3 && !(dma_ok && split == 1)) cfg = 0;               // the 256x128 tile exists only as an unsplit LDS-DMA kernel
-  if (stats_tile_rows) *stats_tile_rows = p.stats ? (cfg == 3 ? 256 : cfg == 0 ? 128 : 64) : 0;
+  const int bm = (cfg == 3 || cfg >= 6) ? 256 : (cfg == 1 ? 64 : 128);
+  const int bn = (cfg == 4 || cfg == 6) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (cfg == 1 ? 64 : 128));
+  if (stats_tile_rows) *stats_tile_rows = p.stats ? bm : 0;
   p.slab = ws;
-  const bool dma = dma_ok;
-  if (cfg == 3) {
-    dim3 grid((p.M + 255) / 256, (p.N + 127) / 128, 1);
-    int r = g_var256 == 1 ? launch_dma<256, 128, 32, 2>(p, grid, st, g_zero_page) : launch_dma<256, 128, 32, 3>(p, grid, st, g_zero_page);
-    if (r) return r;
+  dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, split);
+  int r = 0;
+  if (!dma_ok) {
+    if (cfg == 1) {
+      if (fast) igemm_kernel<64, 64, true><<<grid, 256, lds_bytes(64, 64), st>>>(p);
+      else igemm_kernel<64, 64, false><<<grid, 256, lds_bytes(64, 64), st>>>(p);
+    } else {
+      if (fast) igemm_kernel<128, 128, true><<<grid, 256, lds_bytes(128, 128), st>>>(p);
+      else igemm_kernel<128, 128, false><<<grid, 256, lds_bytes(128, 128), st>>>(p);
+    }
+  } else if (cfg == 3) {
+    r = g_var256 == 1 ? launch_dma<256, 128, 32, 2, 2>(p, grid, st, g_zero_page) : launch_dma<256, 128, 32, 3, 2>(p, grid, st, g_zero_page);
+  } else if (cfg == 4) {
+    switch (g_var320) {
+      case 0: r = launch_dma<128, 320, 32, 3>(p, grid, st, g_zero_page); break;       // 84 KB ring = whole-tile epilogue, 1 block / CU
+      case 2: r = launch_dma<128, 320, 64, 2>(p, grid, st, g_zero_page); break;       // 128-byte rows, 112 KB, 1 block / CU
+      case 11: r = launch_dma<128, 320, 32, 2, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
+      case 12: r = launch_dma<128, 320, 32, 2, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
+      default: r = launch_dma<128, 320, 32, 2>(p, grid, st, g_zero_page); break;      // 56 KB ring, two-pass epilogue, 2 blocks / CU
+    }
+  } else if (cfg == 6) {
+    r = launch_dma<256, 320, 64, 2, 4>(p, grid, st, g_zero_page);
+  } else if (cfg == 7) {
+    r = launch_dma<256, 256, 64, 2, 4>(p, grid, st, g_zero_page);
+  } else if (cfg == 5) {
+    switch (g_var256n) {
+      case 0: r = launch_dma<128, 256, 32, 3>(p, grid, st, g_zero_page); break;       // 72 KB, 2 blocks / CU
+      case 2: r = launch_dma<128, 256, 64, 2>(p, grid, st, g_zero_page); break;
+      default: r = launch_dma<128, 256, 32, 2>(p, grid, st, g_zero_page); break;      // 48 KB: two-pass epilogue, 3 blocks / CU by LDS
+    }
   } else if (cfg == 0) {
-    dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, split);
-    if (dma) {
-      int r;
-      int var = g_var128;
-      // 128-byte rows with 2 stages (64 KB, 2 blocks / CU) beat 64-byte rows with 3 stages (48 KB, 3 blocks / CU) once every CU
-      // holds two blocks that cover for each other's exposed loads; below that the deeper ring wins
-      if (g_v128_bk64_tiles > 0 && var == 2 && (long)grid.x * grid.y * grid.z >= g_v128_bk64_tiles) var = 0;
-      switch (var) {
-        case 1: r = launch_dma<128, 128, 64, 3>(p, grid, st, g_zero_page); break;
-        case 2: r = launch_dma<128, 128, 32, 3>(p, grid, st, g_zero_page); break;
-        case 3: r = launch_dma<128, 128, 32, 4>(p, grid, st, g_zero_page); break;
-        case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
-        case 11: r = launch_dma<128, 128, 32, 3, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
-        case 12: r = launch_dma<128, 128, 32, 3, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
-        case 15: r = launch_dma<128, 128, 32, 3, 3>(p, grid, st, g_zero_page); break;   // ablation: activation loads for tap 0 only
-        case 13: r = launch_dma<128, 128, 64, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only, 128-byte rows
-        case 14: r = launch_dma<128, 128, 64, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only, 128-byte rows
-        default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;
-      }
-      if (r) return r;
+    int var = g_var128;
+    // 128-byte rows with 2 stages (64 KB, 2 blocks / CU) beat 64-byte rows with 3 stages (48 KB, 3 blocks / CU) once every CU
+    // holds two blocks that cover for each other's exposed loads; below that the deeper ring wins
+    if (g_v128_bk64_tiles > 0 && var == 2 && (long)grid.x * grid.y * grid.z >= g_v128_bk64_tiles) var = 0;
+    switch (var) {
+      case 1: r = launch_dma<128, 128, 64, 3>(p, grid, st, g_zero_page); break;
+      case 2: r = launch_dma<128, 128, 32, 3>(p, grid, st, g_zero_page); break;
+      case 3: r = launch_dma<128, 128, 32, 4>(p, grid, st, g_zero_page); break;
+      case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
+      case 11: r = launch_dma<128, 128, 32, 3, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
+      case 12: r = launch_dma<128, 128, 32, 3, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
+      case 15: r = launch_dma<128, 128, 32, 3, 2, 3>(p, grid, st, g_zero_page); break;   // ablation: activation loads for tap 0 only
+      default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;
     }
-    else if (fast) igemm_kernel<128, 128, true><<<grid, 256, lds_bytes(128, 128), st>>>(p);
-    else igemm_kernel<128, 128, false><<<grid, 256, lds_bytes(128, 128), st>>>(p);
   } else {
-    dim3 grid((p.M + 63) / 64, (p.N + 63) / 64, split);
-    if (dma) {
-      int r;
-      switch (g_var64) {
-        case 1: r = launch_dma<64, 64, 64, 2>(p, grid, st, g_zero_page); break;
-        case 2: r = launch_dma<64, 64, 64, 4>(p, grid, st, g_zero_page); break;
-        case 3: r = launch_dma<64, 64, 32, 4>(p, grid, st, g_zero_page); break;
-        default: r = launch_dma<64, 64, 64, 3>(p, grid, st, g_zero_page); break;
-      }
-      if (r) return r;
+    switch (g_var64) {
+      case 1: r = launch_dma<64, 64, 64, 2>(p, grid, st, g_zero_page); break;
+      case 2: r = launch_dma<64, 64, 64, 4>(p, grid, st, g_zero_page); break;
+      case 3: r = launch_dma<64, 64, 32, 4>(p, grid, st, g_zero_page); break;
+      default: r = launch_dma<64, 64, 64, 3>(p, grid, st, g_zero_page); break;
     }
-    else if (fast) igemm_kernel<64, 64, true><<<grid, 256, lds_bytes(64, 64), st>>>(p);
-    else igemm_kernel<64, 64, false><<<grid, 256, lds_bytes(64, 64), st>>>(p);
   }
+  if (r) return r;
   if (split > 1) {
     size_t total = (size_t)p.M * ((p.N + 3) / 4);
     int blocks = (int)((total + 255) / 256);

@@ -149,6 +149,15 @@ struct CtrlDev {
   float* lb_acc = nullptr;        // [npairs][nslots][2][tokens]
 };
 
+// Text K / V cache: the cross-attention keys / values depend only on the text context, which is constant over a denoising loop
+// (to_k / to_v of attention.py:230-234 applied to encoder_hidden_states): computed once per loop for the 16 transformer blocks.
+struct TextKV {
+  std::vector<half_t*> k, vt;     // per transformer block in execution order: [rows][T][hd], [rows][hd][ldv]
+  char* base = nullptr; size_t cap = 0;
+  int rows = 0;                   // rows the cache holds (0 = invalid)
+  bool use = false;               // the forward in flight reads the cache instead of projecting the context
+};
+
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; int M, N, K, ksize; };
 
 struct pnpi_ctx {
@@ -165,7 +174,11 @@ struct pnpi_ctx {
   float* temb_table;      // [n_train][C0] fp32 sinusoid table
   float* temb_h;          // [4*C0]
   float* temb_emb;        // [4*C0]
-  float* bias_eff;        // [temb_total]
+  float* bias_eff;        // [temb_total] of the forward in flight (points into bias_tab once cached)
+  float* bias_scratch;    // [temb_total]
+  float* bias_tab = nullptr;          // [n_train][temb_total]: conv1 bias + time embedding per TIMESTEP, filled on first use -- it depends
+  std::vector<char> bias_valid;       // on t and the weights only, so every later forward at that timestep launches no GEMV
+  TextKV tkv;
   std::unordered_map<std::string, Slot> slots;
   UNetW unet;
   VaeW vae;

@@ -107,32 +107,52 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
   }
 }
 
+// y = x * scale + shift (+ SiLU).  A thread owns one 8-channel vector position (its 16 scale / shift values stay in registers)
+// and walks pixels, four independent 16-byte loads in flight; a block covers `ppb` consecutive pixels of one batch item, so a
+// wavefront reads and writes whole contiguous rows.  No LDS, no barrier.
 __global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1,
-                                                       int C2, int HW, int napply, const float* __restrict__ ss, int silu,
+                                                       int C2, int HW, int ppb, const float* __restrict__ ss, int silu,
                                                        half_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int C = C1 + C2, C8 = C >> 3;
-  float* s_ss = reinterpret_cast<float*>(smem_raw);  // [C][2]
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_ss[i] = ss[(size_t)b * C * 2 + i];
-  __syncthreads();
-  const int ppc = (HW + napply - 1) / napply;
-  const int p0 = blockIdx.y * ppc, p1 = min(HW, p0 + ppc);
-  const int nvec = (p1 > p0 ? p1 - p0 : 0) * C8;
-  for (int idx = threadIdx.x; idx < nvec; idx += blockDim.x) {
-    int pix = p0 + idx / C8;
-    int c = (idx % C8) * 8;
+  const int CL = C8 < 256 ? C8 : 256, TP = 256 / CL;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tc = tid % CL, tp = tid / CL;
+  if (tp >= TP) return;
+  const int p0 = blockIdx.y * ppb, p1 = min(HW, p0 + ppb);
+  for (int cv = tc; cv < C8; cv += CL) {
+    const int c = cv * 8;
+    float sc[8], sh[8];
+    {
+      const floatx4* sp = reinterpret_cast<const floatx4*>(ss + ((size_t)b * C + c) * 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { floatx4 v = sp[j]; sc[2 * j] = v[0]; sh[2 * j] = v[1]; sc[2 * j + 1] = v[2]; sh[2 * j + 1] = v[3]; }
+    }
     const half_t* src; int ld, cc;
     if (c < C1) { src = x1; ld = C1; cc = c; } else { src = x2; ld = C2; cc = c - C1; }
-    half8 v = ldg_half8(src + ((size_t)b * HW + pix) * ld + cc);
-    half8 o;
+    const half_t* base = src + (size_t)b * HW * ld + cc;
+    half_t* obase = out + (size_t)b * HW * C + c;
+    auto xf = [&](half8 v) {
+      half8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f = (float)v[j] * s_ss[(c + j) * 2] + s_ss[(c + j) * 2 + 1];
-      if (silu) f = silu_f(f);
-      o[j] = (half_t)f;
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[j] * sc[j] + sh[j];
+        if (silu) f = silu_f(f);
+        o[j] = (half_t)f;
+      }
+      return o;
+    };
+    int pix = p0 + tp;
+    for (; pix + 3 * TP < p1; pix += 4 * TP) {
+      half8 v0 = ldg_half8(base + (size_t)pix * ld);
+      half8 v1 = ldg_half8(base + (size_t)(pix + TP) * ld);
+      half8 v2 = ldg_half8(base + (size_t)(pix + 2 * TP) * ld);
+      half8 v3 = ldg_half8(base + (size_t)(pix + 3 * TP) * ld);
+      *reinterpret_cast<half8*>(obase + (size_t)pix * C) = xf(v0);
+      *reinterpret_cast<half8*>(obase + (size_t)(pix + TP) * C) = xf(v1);
+      *reinterpret_cast<half8*>(obase + (size_t)(pix + 2 * TP) * C) = xf(v2);
+      *reinterpret_cast<half8*>(obase + (size_t)(pix + 3 * TP) * C) = xf(v3);
     }
-    *reinterpret_cast<half8*>(out + ((size_t)b * HW + pix) * C + c) = o;
+    for (; pix < p1; pix += TP) *reinterpret_cast<half8*>(obase + (size_t)pix * C) = xf(ldg_half8(base + (size_t)pix * ld));
   }
 }
 
@@ -213,7 +233,14 @@ static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, i
 }
 
 static int gn_nchunk(int HW) { int n = HW / 64; if (n < 1) n = 1; if (n > 128) n = 128; return n; }
-static int gn_napply(int HW) { int n = HW / 16; if (n < 1) n = 1; if (n > 1024) n = 1024; return n; }
+// pixels per apply block: every thread gets >= 8 pixels of its vector position where the map allows, >= ~8 blocks per CU overall
+static int gn_ppb(int B, int HW, int C) {
+  const int C8 = C >> 3, CL = C8 < 256 ? C8 : 256, TP = 256 / CL;
+  int ppb = 8 * TP;
+  while (ppb > TP && (long)B * ((HW + ppb - 1) / ppb) < 2048) ppb >>= 1;
+  if (ppb < TP) ppb = TP;
+  return ppb;
+}
 
 // partial: fp32 scratch of at least B * (nchunk * G * 2 + C * 2) floats
 int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
@@ -228,8 +255,8 @@ int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, 
   size_t lds1 = (size_t)TP * C * 2 * sizeof(float);
   gn_stats_kernel<<<dim3(B, nchunk), 256, lds1, st>>>(x1, x2, C1, C2, HW, G, nchunk, partial);
   gn_finalize_kernel<<<B, 256, 0, st>>>(partial, C, HW, G, nchunk, eps, gamma, beta, ss);
-  const int napply = gn_napply(HW);
-  gn_apply_kernel<<<dim3(B, napply), 256, (size_t)2 * C * sizeof(float), st>>>(x1, x2, C1, C2, HW, napply, ss, silu, out);
+  const int ppb = gn_ppb(B, HW, C);
+  gn_apply_kernel<<<dim3(B, (HW + ppb - 1) / ppb), 256, 0, st>>>(x1, x2, C1, C2, HW, ppb, ss, silu, out);
   return (int)hipGetLastError();
 }
 
@@ -268,6 +295,87 @@ __global__ void __launch_bounds__(256) gn_finalize_tiles_kernel(const float* __r
   }
 }
 
+// One-launch form of finalize + apply for the statistics-fused path: every block first reduces the per-(m-tile, channel) partial sums
+// of its batch item to the G group statistics (8 lanes per group, fixed order: strided, then a 3-step butterfly), then applies
+// y = (x - mean) * rstd * gamma + beta (+ SiLU) to its pixel range.  The partials are C * tiles * 8 bytes per batch item (82 KB at
+// 64 x 64 x 320) and L2-resident, so a few hundred blocks re-reading them cost less than a second dependent launch.
+__global__ void __launch_bounds__(256) gn_fin_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1, int C2,
+                                                           int HW, int ppb, const float* __restrict__ st1, int tpb1,
+                                                           const float* __restrict__ st2, int tpb2, int G, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                           half_t* __restrict__ out) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int C = C1 + C2, C8 = C >> 3, cpg = C / G;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int g = g0 + (tid >> 3), sub = tid & 7;
+    float s = 0.f, q = 0.f;
+    if (g < G) {
+      for (int cl = 0; cl < cpg; ++cl) {
+        const int c = g * cpg + cl;
+        const float* st; int cs, cc, tpb;
+        if (c < C1) { st = st1; cs = C1; cc = c; tpb = tpb1; } else { st = st2; cs = C2; cc = c - C1; tpb = tpb2; }
+        const float* base = st + ((size_t)b * tpb * cs + cc) * 2;
+        for (int t = sub; t < tpb; t += 8) { s += base[(size_t)t * cs * 2]; q += base[(size_t)t * cs * 2 + 1]; }
+      }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if (g < G && sub == 0) {
+      const float n = (float)HW * (float)cpg;
+      const float mean = s / n;
+      float var = q / n - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      s_mean[g] = mean;
+      s_rstd[g] = rsqrtf(var + eps);
+    }
+  }
+  __syncthreads();
+  const int CL = C8 < 256 ? C8 : 256, TP = 256 / CL;
+  const int tc = tid % CL, tp = tid / CL;
+  if (tp >= TP) return;
+  const int p0 = blockIdx.y * ppb, p1 = min(HW, p0 + ppb);
+  for (int cv = tc; cv < C8; cv += CL) {
+    const int c = cv * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c + j) / cpg;
+      sc[j] = s_rstd[g] * gamma[c + j];
+      sh[j] = beta[c + j] - s_mean[g] * sc[j];
+    }
+    const half_t* src; int ld, cc;
+    if (c < C1) { src = x1; ld = C1; cc = c; } else { src = x2; ld = C2; cc = c - C1; }
+    const half_t* base = src + (size_t)b * HW * ld + cc;
+    half_t* obase = out + (size_t)b * HW * C + c;
+    auto xf = [&](half8 v) {
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[j] * sc[j] + sh[j];
+        if (silu) f = silu_f(f);
+        o[j] = (half_t)f;
+      }
+      return o;
+    };
+    int pix = p0 + tp;
+    for (; pix + 3 * TP < p1; pix += 4 * TP) {
+      half8 v0 = ldg_half8(base + (size_t)pix * ld);
+      half8 v1 = ldg_half8(base + (size_t)(pix + TP) * ld);
+      half8 v2 = ldg_half8(base + (size_t)(pix + 2 * TP) * ld);
+      half8 v3 = ldg_half8(base + (size_t)(pix + 3 * TP) * ld);
+      *reinterpret_cast<half8*>(obase + (size_t)pix * C) = xf(v0);
+      *reinterpret_cast<half8*>(obase + (size_t)(pix + TP) * C) = xf(v1);
+      *reinterpret_cast<half8*>(obase + (size_t)(pix + 2 * TP) * C) = xf(v2);
+      *reinterpret_cast<half8*>(obase + (size_t)(pix + 3 * TP) * C) = xf(v3);
+    }
+    for (; pix < p1; pix += TP) *reinterpret_cast<half8*>(obase + (size_t)pix * C) = xf(ldg_half8(base + (size_t)pix * ld));
+  }
+}
+
+static int g_gn_inline_rows = 1 << 20;   // statistics-fused GroupNorm: one launch (finalize inside apply) up to this many B*HW rows
+void norm_set_tuning_gn_inline_rows(int v) { g_gn_inline_rows = v; }
+
 int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                            const float* beta, int silu, half_t* out, const float* st1, int tpb1, const float* st2, int tpb2,
                            float* scratch, hipStream_t st) {
@@ -278,10 +386,20 @@ int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, i
   static const int small_min_blocks = getenv("PNPI_GN_SMALL_MIN") ? atoi(getenv("PNPI_GN_SMALL_MIN")) : 0;
   if (gn_small_ok(C1, C2, HW, G) && B * G >= small_min_blocks)
     return launch_gn_small(x1, x2, C1, C2, B, HW, G, eps, gamma, beta, silu, out, st);
+  if ((long)B * HW <= g_gn_inline_rows) {
+    // ~2 blocks per CU, each with enough pixels to amortise its own reduction of the partials
+    const int C8 = C >> 3, CL = C8 < 256 ? C8 : 256, TP = 256 / CL;
+    int ppb = (int)(((long)B * HW + 511) / 512);
+    ppb = ((ppb + TP - 1) / TP) * TP;
+    if (ppb < 4 * TP) ppb = 4 * TP;
+    gn_fin_apply_kernel<<<dim3(B, (HW + ppb - 1) / ppb), 256, 0, st>>>(x1, x2, C1, C2, HW, ppb, st1, tpb1, st2, x2 ? tpb2 : 1, G, eps, gamma,
+                                                                     beta, silu, out);
+    return (int)hipGetLastError();
+  }
   float* ss = scratch;   // [B][C][2]
   gn_finalize_tiles_kernel<<<dim3(B, G), 256, 0, st>>>(st1, C1, tpb1, st2, C2, tpb2, HW, G, eps, gamma, beta, ss);
-  const int napply = gn_napply(HW);
-  gn_apply_kernel<<<dim3(B, napply), 256, (size_t)2 * C * sizeof(float), st>>>(x1, x2, C1, C2, HW, napply, ss, silu, out);
+  const int ppb = gn_ppb(B, HW, C);
+  gn_apply_kernel<<<dim3(B, (HW + ppb - 1) / ppb), 256, 0, st>>>(x1, x2, C1, C2, HW, ppb, ss, silu, out);
   return (int)hipGetLastError();
 }
 

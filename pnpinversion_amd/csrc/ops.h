@@ -34,6 +34,7 @@ void gemm_defaults(GemmP& p);
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0,
                  int* cfg_used = nullptr, int* stats_tile_rows = nullptr);
 int igemm_init();  // sets dynamic-LDS attributes once
+int igemm_set_tuning(const char* key, int value);   // process-wide tuning knobs; 0 on success, -1 unknown key
 void igemm_set_dma(int on);  // 1 (default): LDS-DMA kernel where applicable; 0: register-staged v1 kernel everywhere
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -47,6 +48,7 @@ int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, 
 int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps,
                            const float* gamma, const float* beta, int silu, half_t* out, const float* st1, int tpb1,
                            const float* st2, int tpb2, float* scratch, hipStream_t st);
+void norm_set_tuning_gn_inline_rows(int v);   // tuning "gn_inline_rows"
 int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamma, const float* beta, half_t* out,
                      hipStream_t st);
 int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st);       // x [M][2I] -> out [M][I]

@@ -190,8 +190,14 @@ class NativeEngine:
                 for i, n in enumerate(_capi.KC_NAMES)}
 
     # ---- level 1
+    def text_kv_precompute(self, context):
+        """Project the text context to the 16 cross-attention K / V pairs once; unet(..., context=None) then reads them."""
+        ctx = self._f32(context)
+        self._call("pnpi_text_kv_precompute", _p(ctx), ctx.shape[0])
+        self._keep_ctx = ctx
+
     def unet(self, latents, t, context, rows_per_image=1, ctrls=None, cur_step=0):
-        lat, ctx = self._f32(latents), self._f32(context)
+        lat, ctx = self._f32(latents), (self._f32(context) if context is not None else None)
         rows = lat.shape[0]
         out = torch.empty_like(lat)
         arr = _desc_array(ctrls)

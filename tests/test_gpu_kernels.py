@@ -33,6 +33,10 @@ def h16(*shape, scale=1.0, seed=0):
     (130, 70, 72, -1, 0), (4096, 320, 320, -1, 0), (308, 640, 768, -1, 0), (64, 1280, 5120, -1, 0),
     (1, 8, 8, -1, 0), (33, 4, 2880, 1, 0), (100, 36, 1032, 2, 3),
     (512, 256, 128, 3, 0), (700, 320, 640, 3, 0),        # 256x128 tile (ragged M and N)
+    (4096, 320, 320, 4, 0), (700, 640, 640, 4, 0), (300, 200, 128, 4, 0), (130, 328, 64, 4, 0),     # 128x320 tile, ragged M / N
+    (512, 320, 2048, 4, 4), (1000, 1280, 960, 4, 2),                                                 # 128x320 tile, split-K
+    (256, 256, 512, 5, 0), (1000, 768, 320, 5, 0), (77, 520, 192, 5, 0), (512, 512, 1024, 5, 2),     # 128x256 tile
+    (1000, 640, 640, 6, 0), (300, 330, 128, 6, 0), (700, 512, 256, 7, 0),                            # 8-wave 256x320 / 256x256 tiles
 ])
 def test_gemm(ctx, M, N, K, cfg, split):
     a = h16(M, K, seed=1)
@@ -44,6 +48,67 @@ def test_gemm(ctx, M, N, K, cfg, split):
     ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, 0.5, ptr(bias), ptr(res), ptr(out), ldo, 1 << 30, None, 0, 0, 1, cfg, split)
     ref = 0.5 * (a.float() @ w.float().t()) + bias + res.float()
     assert rel_err(out[:, :N], ref) < 2e-3, (rel_err(out[:, :N], ref), max_err(out[:, :N], ref))
+
+
+@pytest.mark.parametrize("key,val,cfg", [("igemm_v320", 0, 4), ("igemm_v320", 2, 4), ("igemm_v256n", 0, 5), ("igemm_v256n", 2, 5)])
+def test_gemm_wide_tile_variants(ctx, key, val, cfg):
+    """Non-default variants of the wide tiles (default 1 = two-stage ring of 64-byte rows with the two-pass LDS epilogue):
+    0 = three stages / whole-tile epilogue, 2 = 128-byte rows."""
+    M, N, K = 900, 640, 704
+    a, w = h16(M, K, seed=21), h16(N, K, scale=1.0 / math.sqrt(K), seed=22)
+    bias, res = torch.randn(N, device=DEV), h16(M, N, seed=23)
+    out = torch.zeros(M, N, dtype=torch.half, device=DEV)
+    lib = ctx.lib
+    assert lib.pnpi_set_tuning(key.encode(), val) == 0
+    try:
+        ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, 1.0, ptr(bias), ptr(res), ptr(out), N, 1 << 30, None, 0, 0, 1, cfg, 0)
+        torch.cuda.synchronize()
+    finally:
+        assert lib.pnpi_set_tuning(key.encode(), 1) == 0
+    ref = a.float() @ w.float().t() + bias + res.float()
+    assert rel_err(out, ref) < 2e-3, rel_err(out, ref)
+    assert lib.pnpi_set_tuning(b"no_such_knob", 1) != 0
+
+
+@pytest.mark.parametrize("cfg,N,v320", [(0, 320, 0), (1, 192, 0), (4, 320, 0), (4, 640, 1), (5, 512, 0), (5, 256, 1), (6, 320, 0), (7, 256, 0)])
+def test_conv_epilogue_groupnorm_statistics(ctx, cfg, N, v320):
+    """The per-(m-tile, channel) sum / sum-of-squares partials a conv epilogue hands to the consumer GroupNorm: fp32 sums of the
+    STORED fp16 values, every tile configuration (incl. the two-pass epilogue of the 2-stage wide tiles), ragged last m-tile."""
+    B, Cin, H = 3, 64, 20                       # M = 1200 rows: ragged for 64- and 128-row tiles
+    x = h16(B, Cin, H, H, seed=31)
+    w = h16(N, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin), seed=32)
+    bias = torch.randn(N, device=DEV)
+    out = torch.zeros(B, H, H, N, dtype=torch.half, device=DEV)
+    M = B * H * H
+    stats = torch.full(((M + 63) // 64, N, 2), float("nan"), device=DEV)
+    rows = C.c_int(0)
+    xn, wp = nhwc(x), pack_w(w)
+    for key in (b"igemm_v320", b"igemm_v256n"):
+        assert ctx.lib.pnpi_set_tuning(key, v320) == 0
+    try:
+        ctx.call("pnpi_op_conv_stats", ptr(xn), None, Cin, 0, B, H, H, 3, 1, 1, 0, H, H, ptr(wp), ptr(bias), None, N, ptr(out), cfg, 0,
+                 ptr(stats), C.byref(rows))
+        torch.cuda.synchronize()
+    finally:
+        for key in (b"igemm_v320", b"igemm_v256n"):
+            ctx.lib.pnpi_set_tuning(key, 1)
+    tr = rows.value
+    assert tr == (64 if cfg == 1 else (256 if cfg >= 6 else 128))
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-3
+    o = out.reshape(M, N).float()
+    nt = (M + tr - 1) // tr
+    for t in range(nt):
+        blk = o[t * tr:(t + 1) * tr]
+        assert torch.allclose(stats[t, :, 0], blk.sum(0), rtol=1e-5, atol=1e-3), t
+        assert torch.allclose(stats[t, :, 1], (blk * blk).sum(0), rtol=1e-5, atol=1e-3), t
+    # bit-reproducible: a second launch gives the same bits (fixed summation order, no atomics)
+    stats2 = torch.zeros_like(stats)
+    ctx.call("pnpi_op_conv_stats", ptr(xn), None, Cin, 0, B, H, H, 3, 1, 1, 0, H, H, ptr(wp), ptr(bias), None, N, ptr(out), cfg, 0,
+             ptr(stats2), C.byref(rows))
+    torch.cuda.synchronize()
+    if v320 == 1:
+        assert torch.equal(stats[:nt], stats2[:nt])
 
 
 def test_gemm_transposed_region(ctx):
@@ -86,6 +151,13 @@ def pack_w(w):  # [N, C, kh, kw] -> [N, kh*kw*C] tap-major
     (4, 1280, 0, 8, 128, 1, 1, 0, 2, 4),      # deep K, split-K
     (2, 128, 64, 8, 4, 1, 1, 0, -1, 0),       # tiny N (conv_out style), concat with generic... C1=128 fast
     (3, 64, 64, 16, 192, 1, 1, 0, 3, 0),      # 256x128 tile, concat, ragged M (768 rows) and N
+    (3, 64, 64, 16, 320, 1, 1, 0, 4, 0),      # 128x320 tile, concat
+    (2, 320, 0, 16, 640, 1, 1, 0, 4, 0),      # 128x320 tile, two n-tiles
+    (2, 64, 0, 8, 320, 1, 1, 1, 4, 0),        # 128x320 tile with the folded upsample
+    (2, 128, 0, 16, 256, 2, 1, 0, 5, 0),      # 128x256 tile, stride 2
+    (4, 1280, 0, 8, 320, 1, 1, 0, 4, 6),      # 128x320 tile, deep K, split-K
+    (3, 64, 64, 16, 320, 1, 1, 0, 6, 0),      # 256x320 tile (8 waves), concat, ragged M
+    (2, 128, 0, 16, 256, 1, 1, 0, 7, 0),      # 256x256 tile (8 waves)
     (2, 64, 0, 8, 64, 1, 1, 1, 3, 0),         # 256x128 tile with the folded upsample
 ])
 def test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
@@ -175,9 +247,19 @@ def test_geglu(ctx):
     assert rel_err(out, a * F.gelu(g)) < 2e-3
 
 
+@pytest.mark.parametrize("force", [-1, 0, 1, 4, 5, 6])
 @pytest.mark.parametrize("M,K,I", [(4096, 320, 1280), (1024, 640, 2560), (200, 1280, 5120), (64, 64, 64)])
-def test_gemm_fused_geglu(ctx, M, K, I):
-    """GEGLU.forward (my_diffusers/models/attention.py:331-333): proj -> chunk -> x * gelu(gate), fused into the GEMM epilogue."""
+def test_gemm_fused_geglu(ctx, M, K, I, force):
+    """GEGLU.forward (my_diffusers/models/attention.py:331-333): proj -> chunk -> x * gelu(gate), fused into the GEMM epilogue
+    of every tile configuration (force = tile configuration of launch_igemm; -1 = the cost model's choice)."""
+    assert ctx.lib.pnpi_set_tuning(b"igemm_force_cfg", force) == 0
+    try:
+        _geglu_case(ctx, M, K, I)
+    finally:
+        ctx.lib.pnpi_set_tuning(b"igemm_force_cfg", -1)
+
+
+def _geglu_case(ctx, M, K, I):
     a = h16(M, K, seed=51)
     w = h16(2 * I, K, scale=1.0 / math.sqrt(K), seed=52)
     bias = torch.randn(2 * I, device=DEV)

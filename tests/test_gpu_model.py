@@ -49,6 +49,48 @@ def test_unet_tiny(tiny, rows, t):
     assert rel(got, ref) < 4e-3, rel(got, ref)
 
 
+def test_text_kv_cache_and_timestep_bias_table_are_exact(tiny):
+    """pnpi_text_kv_precompute + pnpi_unet_forward(context=NULL), and the per-timestep (conv1 bias + time embedding) table:
+    the same GEMM / GEMV launches moved out of the forward, so the result is bit-identical to the in-forward evaluation."""
+    cfg, usd, vsd, eng = tiny
+    lat = _lat(cfg, 4, 41)
+    ctx = weights.synth_context(cfg, 4, seed=42)
+    lib = eng.lib
+    lib.pnpi_set_tuning(b"temb_cache", 0)
+    ref = eng.unet(lat, 777, ctx).clone()
+    lib.pnpi_set_tuning(b"temb_cache", 1)
+    first, again = eng.unet(lat, 777, ctx).clone(), eng.unet(lat, 777, ctx).clone()      # fills the table row, then reads it
+    assert torch.equal(first, ref) and torch.equal(again, ref)
+    eng.text_kv_precompute(ctx)
+    c0 = eng.counters()
+    cached = eng.unet(lat, 777, None)
+    c1 = eng.counters()
+    assert torch.equal(cached, ref)
+    assert c1["unet_sample_forwards_cached_kv"] - c0["unet_sample_forwards_cached_kv"] == 4 and c0["text_kv_rows"] >= 4
+    with pytest.raises(Exception, match="pnpi_text_kv_precompute"):
+        eng.unet(lat[:2], 777, None)                                                     # cache holds 4 rows
+    # a weight (re)load invalidates both caches
+    eng.load_state_dict(usd, None)
+    with pytest.raises(Exception, match="pnpi_text_kv_precompute"):
+        eng.unet(lat, 777, None)
+    assert torch.equal(eng.unet(lat, 777, ctx), ref)
+    # level-2 loops: cached (default) vs projecting the context inside every forward
+    from pnpinversion_amd.p2p.scheduler_dev import DDIMSchedulerDev
+    sch = DDIMSchedulerDev(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    sch.bind(eng)
+    sch.set_timesteps(3)
+    ts = sch.timesteps.numpy()
+    a = eng.ddim_invert(lat[:1], ctx[2:3], ts).clone()
+    nl_a, lat_a = eng.direct_edit(a, ctx[None], [None], ts, 7.5)          # 8 rows: offsets + one guidance pass
+    lib.pnpi_set_tuning(b"text_kv", 0)
+    try:
+        b = eng.ddim_invert(lat[:1], ctx[2:3], ts)
+        nl_b, lat_b = eng.direct_edit(b, ctx[None], [None], ts, 7.5)
+    finally:
+        lib.pnpi_set_tuning(b"text_kv", 1)
+    assert torch.equal(a, b) and torch.equal(nl_a, nl_b) and torch.equal(lat_a, lat_b)
+
+
 def test_vae_tiny(tiny):
     cfg, usd, vsd, eng = tiny
     g = torch.Generator().manual_seed(9)

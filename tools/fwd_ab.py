@@ -1,0 +1,47 @@
+"""A/B of whole UNet forwards under the process-wide tuning knobs (pnpi_set_tuning), one engine, interleaved rounds.
+usage: fwd_ab.py [rows ...]   (default 1 12) -> prints ms / forward per arm, writes gpurun_out/fwd_ab.json"""
+import json, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pnpinversion_amd import weights
+from pnpinversion_amd.config import SD1
+from pnpinversion_amd.engine import NativeEngine
+rows_list = [int(a) for a in sys.argv[1:]] or [1, 12]
+eng = NativeEngine(SD1, max_unet_rows=max(rows_list + [4]), max_vae_images=1)
+eng.load_state_dict({k: v.cuda() for k, v in weights.unet_state_dict(SD1, 0).items()}, {k: v.cuda() for k, v in weights.vae_state_dict(SD1, 0).items()})
+lib = eng.lib
+DEFAULTS = {"igemm_wide": 1, "gn_inline_rows": 1 << 20, "igemm_force_cfg": -1, "igemm_v320": 1, "igemm_v256n": 1}
+ARMS = {"default": {}, "no_wide": {"igemm_wide": 0}, "gn_two_launch": {"gn_inline_rows": 0}, "force128": {"igemm_force_cfg": 0},
+        "v320_0": {"igemm_v320": 0}, "v256n_0": {"igemm_v256n": 0}}
+def setk(d):
+    for k, v in {**DEFAULTS, **d}.items(): assert lib.pnpi_set_tuning(k.encode(), v) == 0, k
+out = {}
+for rows in rows_list:
+    lat = torch.randn(rows, 4, 64, 64, device="cuda"); ctx = torch.randn(rows, 77, 768, device="cuda")
+    n = 30 if rows <= 4 else 12
+    res = {a: [] for a in ARMS}; res["kv_cached"] = []
+    for rnd in range(3):
+        for arm, kn in ARMS.items():
+            setk(kn)
+            for _ in range(2): eng.unet(lat, 500, ctx)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n): eng.unet(lat, 500, ctx)
+            torch.cuda.synchronize(); res[arm].append((time.perf_counter() - t0) / n * 1e3)
+        setk({})
+        eng.text_kv_precompute(ctx)
+        for _ in range(2): eng.unet(lat, 500, None)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): eng.unet(lat, 500, None)
+        torch.cuda.synchronize(); res["kv_cached"].append((time.perf_counter() - t0) / n * 1e3)
+    out[rows] = {a: min(v) for a, v in res.items()}
+    print("rows=%d ms/forward (min of 3 rounds):" % rows, " ".join("%s=%.3f" % (a, min(v)) for a, v in res.items()), flush=True)
+    setk({})
+    if os.environ.get("FWD_AB_DUMP"):
+        os.environ["PNPI_PROFILE_DUMP"] = "gpurun_out/dump_r2_b%d.csv" % rows
+        eng.text_kv_precompute(ctx)
+        eng.profile_begin()
+        for _ in range(3): eng.unet(lat, 500, None)
+        cls = eng.profile_end()
+        out[rows]["classes"] = {k: (v["launches"] // 3, round(v["total_ms"] / 3, 3)) for k, v in cls.items() if v["launches"]}
+        print("  classes (launches, ms per forward):", out[rows]["classes"], flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/fwd_ab.json", "w"), indent=1)
