@@ -98,6 +98,18 @@ typedef struct {
                                       self-attention reads K and V of the source row of their CFG half (masactrl.py:63-69) */
 } pnpi_ctrl_desc;
 
+/* Reconstruction guidance of the proximal-guidance loop (models/p2p/proximal_guidance_forward.py:48-51,60-72 with
+ * DDIMSchedulerDev.step's ref_image / recon_lr / recon_mask branch, models/p2p/scheduler_dev.py:68-76): at the steps with
+ * (recon_t > 0 and t < recon_t) or (recon_t < 0 and t > -recon_t) the predicted x0 is pulled towards the encoded source image where
+ * the (shrunk) CFG difference is not above the proximal threshold:  mask_edit = dilate(|delta| > thr, kernel 2*dilate_mask+1);
+ * pred_x0 -= recon_lr * (pred_x0 - ref_image) * (1 - mask_edit).  Only meaningful with prox != 0. */
+typedef struct {
+  const float* ref_image;          /* device [nimg][4][h][w]: image_enc_latent (0.18215 * VAE posterior mean of the source image) */
+  float recon_lr;
+  int recon_t;
+  int dilate_mask;                 /* radius of the max-pool dilation of mask_edit; 0 = none */
+} pnpi_recon_desc;
+
 typedef struct {
   uint64_t unet_sample_forwards;   /* number of UNet batch rows evaluated (x 803.27 GFLOP each for SD-1.x) */
   uint64_t unet_calls;
@@ -171,7 +183,8 @@ int pnpi_ddim_prev_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, 
 int pnpi_cfg_ddim_prev(pnpi_ctx* ctx, const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems,
                        float guidance_scale, int t, int step_ratio, const float* noise_loss, int offset_rows,
                        const float* target, float offset_scale, float* offset_out, float* x_out,
-                       const float* prox_threshold /*[nimg] device, nullable*/, int prox /*0 none, 1 l0, 2 l1*/);
+                       const float* prox_threshold /*[nimg] device, nullable*/, int prox /*0 none, 1 l0, 2 l1*/,
+                       const pnpi_recon_desc* recon /* nullable; applied when its recon_t window contains t */);
 /* threshold of the proximal-guidance step (proximal_guidance_forward.py:41,53): torch.quantile(|eps_c - eps_u|, q) with the
  * default linear interpolation over the rows of each image; eps [nimg][2R][E] -> thr_out [nimg] (device) */
 int pnpi_prox_threshold(pnpi_ctx* ctx, const float* eps, int nimg, int rows_per_img, size_t row_elems, float quantile,
@@ -200,11 +213,11 @@ int pnpi_ddim_invert_cfg(pnpi_ctx* ctx, const float* z0, int nimg, const float* 
  * latents_out [nimg][2][4][h][w].  ctrl_host: nullable or [nimg].
  * prox 1 ('l0') / 2 ('l1'): the proximal-guidance step of proximal_guidance_forward.py:39-64 -- the CFG difference is
  * soft-thresholded at quantile `quantile` of its magnitude over the image's two rows (torch.quantile, linear); a
- * quantile <= 0 means the fixed threshold -quantile.  prox 0: plain CFG. */
+ * quantile <= 0 means the fixed threshold -quantile.  prox 0: plain CFG.  recon (nullable): reconstruction guidance. */
 int pnpi_edit_loop(pnpi_ctx* ctx, const float* x_T /*[nimg][4][h][w]*/, int nimg, const float* context4,
                    const float* noise_loss /*[nsteps][nimg][2][...], nullable*/, int offset_rows,
                    const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* timesteps_host, float guidance_scale,
-                   int prox, float quantile, float* latents_out);
+                   int prox, float quantile, const pnpi_recon_desc* recon, float* latents_out);
 
 /* The denoising half of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) as ONE loop: offset_calculate
  * (inversion.py:375-391) and npass direct_inversion_p2p_guidance_forward passes (p2p_guidance_forward.py:135-173; the

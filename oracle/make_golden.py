@@ -17,6 +17,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
   e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
   e2e_proximal.npz     P2PEditor("negative-prompt-inversion+proximal-guidance") with the sweep script's arguments (l0) and l1
+  e2e_proximal_recon.npz  the same method with use_reconstruction_guidance=True (masked pred-x0 pull + dilated edit mask), 4 steps
   clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
   method_dispatch.json P2PEditor.__call__'s routing of its 39 method strings (handler + method-specific arguments)
 """
@@ -327,6 +328,56 @@ def proximal(steps=2):
     np.savez_compressed(os.path.join(OUT, "e2e_proximal.npz"), **out)
 
 
+def proximal_recon(steps=4):
+    """P2PEditor("negative-prompt-inversion+proximal-guidance") with use_reconstruction_guidance=True (models/p2p_editor.py:324-413 ->
+    proximal_guidance_forward.py:48-51,60-72 -> DDIMSchedulerDev.step's ref_image branch, scheduler_dev.py:68-76): 4 steps
+    (t = 750, 500, 250, 0: the pull towards the encoded source image is active at t < recon_t = 400), dilate_mask = 1, l0 and l1."""
+    ref_shim.install()
+    cfg = SMALL64
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, w0, w1 = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    import models.p2p_editor as pe
+    out = {"steps": np.int64(steps), "src": src, "tgt": tgt, "blend": np.array([w0, w1]), "recon_lr": np.float32(0.5), "recon_t": np.int64(400),
+           "dilate_mask": np.int64(1)}
+    import models.p2p.inversion as inv
+    for prox in ("l0", "l1"):
+        calls = []
+        saved = pe.proximal_guidance_forward
+        saved_inv = inv.NegativePromptInversion.invert
+
+        def spy(*a, **k):
+            r = saved(*a, **k)
+            calls.append(r[0].clone().numpy())
+            return r
+
+        def spy_inv(self, *a, **k):
+            r = saved_inv(self, *a, **k)
+            out["image_enc_latent"] = r[1].clone().numpy()
+            out["x_stars"] = torch.stack([x.clone() for x in r[2]]).numpy()
+            out["context"] = self.context.clone().numpy().astype(np.float16)
+            return r
+
+        pe.proximal_guidance_forward = spy
+        inv.NegativePromptInversion.invert = spy_inv
+        try:
+            with ref_shim.cuda_to_cpu(), torch.no_grad():
+                panel = ed("negative-prompt-inversion+proximal-guidance", image_path=img, prompt_src=src, prompt_tar=tgt,
+                           guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+                           eq_params={"words": (w1,), "values": (2,)}, proximal=prox, quantile=0.75, use_reconstruction_guidance=True,
+                           recon_lr=0.5, recon_t=400, dilate_mask=1)
+        finally:
+            pe.proximal_guidance_forward = saved
+            inv.NegativePromptInversion.invert = saved_inv
+        assert len(calls) == 2
+        out[prox + "/reconstruct_latent"], out[prox + "/edited_latents"] = calls
+        out[prox + "/edited_image_small"] = np.array(panel)[::4, 3 * 512::4]
+        print("proximal_recon", prox, {k: v.shape for k, v in out.items() if k.startswith(prox + "/")})
+    np.savez_compressed(os.path.join(OUT, "e2e_proximal_recon.npz"), **out)
+
+
 def masactrl(steps=6, start_step=2, start_layer=10):
     """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -416,6 +467,8 @@ if __name__ == "__main__":
         masactrl()
     if "proximal" in which:
         proximal()
+    if "proximal_recon" in which or not sys.argv[1:]:
+        proximal_recon()
     if "clip" in which:
         clip_text()
     if "dispatch" in which:

@@ -263,10 +263,11 @@ def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guid
 
 
 def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timesteps, ac, final, guidance_scale, offset_rows=1,
-                     collect=None, prox=None, quantile=0.7):
+                     collect=None, prox=None, quantile=0.7, recon=None):
     """direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) + ..._diffusion_step (:103-116).
-    prox 'l0' / 'l1': the proximal step of proximal_guidance_diffusion_step (proximal_guidance_forward.py:39-64) with no
-    reference image and no inversion guidance (what the reference's editors reach)."""
+    prox 'l0' / 'l1': the proximal step of proximal_guidance_diffusion_step (proximal_guidance_forward.py:39-64), no inversion
+    guidance (what the reference's editors reach).  recon = dict(ref_image, recon_lr, recon_t, dilate_mask): reconstruction
+    guidance (:48-51,60-72 + DDIMSchedulerDev.step's ref_image / recon_mask branch, scheduler_dev.py:68-76)."""
     n = len(timesteps)
     ratio = len(ac) // n
     nrow = context4.shape[0] // 2
@@ -284,7 +285,19 @@ def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timest
                 d = torch.where(d < 0, d + thr, d)
         e = eu + guidance_scale * d
         a_t, a_p = prev_alphas(ac, final, t, ratio)
-        lat = ddim_move(lat, e, float(a_t), float(a_p))
+        rt = recon["recon_t"] if recon is not None else 0
+        if prox is not None and recon is not None and recon["recon_lr"] > 0 and ((rt > 0 and t < rt) or (rt < 0 and t > -rt)):
+            mask_edit = (d.abs() > thr).float()
+            if recon.get("dilate_mask", 0) > 0:
+                r_ = int(recon["dilate_mask"])
+                mask_edit = F.max_pool2d(mask_edit, 2 * r_ + 1, 1, r_)
+            recon_mask = 1 - mask_edit
+            sa_f, sb_f, sa_t, sb_t = _scalars(float(a_t), float(a_p), lat.dtype)
+            x0 = (lat - sb_f * e) / sa_f
+            x0 = x0 - recon["recon_lr"] * (x0 - recon["ref_image"].expand_as(x0)) * recon_mask
+            lat = sa_t * x0 + sb_t * e
+        else:
+            lat = ddim_move(lat, e, float(a_t), float(a_p))
         if noise_loss_list is not None:
             lat = torch.cat((lat[:offset_rows] + noise_loss_list[i][:offset_rows], lat[offset_rows:]))
         if controller is not None:

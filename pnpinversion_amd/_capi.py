@@ -37,6 +37,10 @@ class CtrlDesc(C.Structure):
     ]
 
 
+class ReconDesc(C.Structure):
+    _fields_ = [("ref_image", C.c_void_p), ("recon_lr", C.c_float), ("recon_t", C.c_int), ("dilate_mask", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [("unet_sample_forwards", C.c_uint64), ("unet_calls", C.c_uint64), ("vae_encodes", C.c_uint64),
                 ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double),
@@ -77,13 +81,13 @@ SYMBOLS = {
     "pnpi_latent2image": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pnpi_ddim_next_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "pnpi_ddim_prev_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
-    "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _i]),
+    "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, C.POINTER(ReconDesc)]),
     "pnpi_prox_threshold": (_i, [_vp, _vp, _i, _i, _sz, _f, _vp]),
     "pnpi_text_encode": (_i, [_vp, _vp, _i, _vp]),
     "pnpi_ddim_invert": (_i, [_vp, _vp, _i, _vp, _i, _ip, _vp]),
     "pnpi_ddim_invert_cfg": (_i, [_vp, _vp, _i, _vp, _vp, _f, _i, _ip, _vp]),
     "pnpi_offset_calculate": (_i, [_vp, _vp, _i, _vp, _i, _ip, _f, _fp, _vp]),
-    "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _i, _f, _vp]),
+    "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _i, _f, C.POINTER(ReconDesc), _vp]),
     "pnpi_direct_edit": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CtrlDesc), _i, _i, _ip, _f, _fp, _vp, _vp]),
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     "pnpi_op_conv_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _ip]),

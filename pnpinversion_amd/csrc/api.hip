@@ -1330,13 +1330,19 @@ int pnpi_ddim_prev_step(pnpi_ctx* c, const float* eps, int t, int ratio, const f
   CK(launch_ddim_move(sample, eps, af, at, n, out, c->st));
   return 0;
 }
+static bool recon_active(const pnpi_recon_desc* rc, int t) {   // proximal_guidance_forward.py:48,60
+  return rc && rc->ref_image && rc->recon_lr > 0.f && ((rc->recon_t > 0 && t < rc->recon_t) || (rc->recon_t < 0 && t > -rc->recon_t));
+}
+
 int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, int rpi, size_t row_elems, float gs, int t, int ratio,
                        const float* noise_loss, int offset_rows, const float* target, float offset_scale, float* offset_out,
-                       float* x_out, const float* prox_threshold, int prox) {
+                       float* x_out, const float* prox_threshold, int prox, const pnpi_recon_desc* recon) {
   if (prox < 0 || prox > 2 || (prox && !prox_threshold)) return fail(c, PNPI_EINVAL, "prox must be 0, or 1 / 2 with a threshold");
   float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+  const bool rc = prox && recon_active(recon, t);
+  const int S = c->cfg.sample_size;
   CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_scale, offset_out, x_out, c->st,
-                          prox_threshold, prox));
+                          prox_threshold, prox, rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, S, S));
   return 0;
 }
 
@@ -1515,7 +1521,8 @@ int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const flo
 }
 
 int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
-                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile, float* latents_out) {
+                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
+                   const pnpi_recon_desc* recon, float* latents_out) {
   if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   const pnpi_model_config& g = c->cfg;
@@ -1547,7 +1554,10 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
     if (prox && quantile > 0.f) CK(launch_quantile_abs_diff(eps, nimg, 2, E, quantile, thr, c->st));
-    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st, prox ? thr : nullptr, prox));
+    const bool rc = prox && recon_active(recon, t);
+    CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st, prox ? thr : nullptr, prox,
+                            rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, g.sample_size,
+                            g.sample_size));
     if (use_ctrl) CKP(apply_local_blend(c, lat, i));
   }
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));

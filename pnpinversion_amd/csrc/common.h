@@ -35,8 +35,20 @@ __device__ __forceinline__ half8 zero_half8() {
 __device__ __forceinline__ half8 ldg_half8(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-// exact (erf) GELU, as torch.nn.functional.gelu default
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// Exact-form (erf) GELU of torch.nn.functional.gelu, x * Phi(x), branch-free: Phi(-|x|) = erfc(|x| / sqrt 2) / 2 by Abramowitz &
+// Stegun 7.1.26 (|error| <= 1.5e-7 absolute -- 4000x below an fp16 ulp of the product) on the raw v_rcp_f32 / v_exp_f32; the
+// library erff costs several hundred cycles per wavefront with its range branches, and the fused GEGLU epilogue evaluates one per
+// output element (63 M per 64 x 64-level feed-forward at 12 rows).
+__device__ __forceinline__ float gelu_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);   // Phi(-|x|)
+  return x * (x >= 0.f ? 1.0f - half_erfc : half_erfc);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

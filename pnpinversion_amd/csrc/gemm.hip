@@ -337,7 +337,9 @@ struct IgemmGeom {
   static constexpr int STATS_B = G * BN * 2 * 4;
   static constexpr int EPASS = (BM * OLD * 2 + STATS_B <= RING) ? 1 : WGM;
   static constexpr int EROWS = BM / EPASS;
-  static constexpr int EPI = EROWS * OLD * 2 + STATS_B;
+  static constexpr int TOLD = EROWS + 8;                        // halfs per staged row of a TRANSPOSED tile ([BN][EROWS + 8])
+  static constexpr int EPI_PLAIN = EROWS * OLD * 2 + STATS_B, EPI_TR = BN * TOLD * 2;
+  static constexpr int EPI = EPI_PLAIN > EPI_TR ? EPI_PLAIN : EPI_TR;
   static constexpr int LDS = RING > EPI ? RING : EPI;
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "DMA instructions must divide evenly over the waves");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % 64 == 0, "wave tile");
@@ -500,10 +502,14 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
     int rd = 0, wr = NST - 1;
     for (int it = 0; it < total; ++it) {
       const int ahead = issued - it - 1;           // chunks issued after the one needed now (0 .. NST-2)
+      static_assert((NST - 2) * LPS <= 63, "vmcnt holds 6 bits");
       if (NST == 2 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
       else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+      else if (ahead == 3 || NST <= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 4 ? 3 : 0) * LPS) : "memory");
+      else if (ahead == 4 || NST <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 5 ? 4 : 0) * LPS) : "memory");
+      else if (ahead == 5 || NST <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 6 ? 5 : 0) * LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 7 ? 6 : 0) * LPS) : "memory");
       __builtin_amdgcn_s_barrier();
       if (ABL == 1) {
         if (issued < total) { issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
@@ -547,6 +553,7 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
     // partial is combined in a FIXED order (rows ascending per thread, then groups ascending): bit-reproducible statistics.
     constexpr int OLD = GEO::OLD, VPR = GEO::VPR, G = GEO::G, EPASS = GEO::EPASS, EROWS = GEO::EROWS;
     half_t* sOut = reinterpret_cast<half_t*>(smem_raw);
+    const bool tr_tile = p.outT != nullptr && n0 >= p.vt_col0;      // block-uniform (the launcher aligns vt_col0 to the tile width)
     const int sv = tid % VPR, sg = tid / VPR;
     const bool s_active = sg < G;
     float cs[8], cq[8];
@@ -557,7 +564,8 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
 #pragma unroll
     for (int e = 0; e < EPASS; ++e) {
       const int r0 = e * EROWS;                         // first tile row of this pass
-      if (p.res) {
+      const bool res_staged = p.res && !p.res_late;
+      if (res_staged) {
         if (s_active)
           for (int r = sg; r < EROWS; r += G) {
             const int m = m0 + r0 + r, n = n0 + sv * 8;
@@ -565,6 +573,43 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
             *reinterpret_cast<half8*>(sOut + r * OLD + sv * 8) = val;
           }
         __syncthreads();
+      }
+      if (tr_tile) {
+        // V^T-style output (columns >= vt_col0 are written transposed per batch item): the tile is staged TRANSPOSED, [BN][EROWS + 8],
+        // and leaves as 16-byte runs of 8 consecutive tokens of one output channel
+        constexpr int TOLD = GEO::TOLD, VPT = EROWS / 8;
+        if (EPASS == 1 || (wave >> 1) == e) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int ml = wm0 - r0 + mi * 32 + (lane & 31);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  float o = acc[mi][ni][4 * g + j] * p.alpha;
+                  if (p.bias && n0 + nl + j < p.N) o += p.bias[n0 + nl + j];
+                  sOut[(nl + j) * TOLD + ml] = (half_t)o;
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+        const int ncol = p.N - p.vt_col0;
+        for (int idx = tid; idx < BN * VPT; idx += NT) {
+          const int nl = idx / VPT, v = idx - nl * VPT;
+          const int n = n0 + nl, m = m0 + r0 + v * 8;
+          if (n < p.N && m < p.M) {
+            const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
+            half_t* dst = (half_t*)p.outT + ((size_t)b * ncol + (n - p.vt_col0)) * p.vt_ld + tok;
+            *reinterpret_cast<half8*>(dst) = *reinterpret_cast<const half8*>(sOut + nl * TOLD + v * 8);
+          }
+        }
+        if (e + 1 < EPASS) __syncthreads();
+        continue;
       }
       if (EPASS == 1 || (wave >> 1) == e) {
 #pragma unroll
@@ -583,7 +628,7 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
                 o[j] = acc[mi][ni][4 * g + j] * p.alpha;
                 if (p.bias && n + j < p.N) o[j] += p.bias[n + j];
               }
-              if (p.res) {
+              if (res_staged) {
                 half4 r4 = *slot;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
@@ -598,10 +643,16 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
       if (!p.geglu) {
         if (s_active) {
           const int n = n0 + sv * 8;
+#pragma unroll 4
           for (int r = sg; r < EROWS; r += G) {
             const int m = m0 + r0 + r;
             if (m < p.M && n < p.N) {
-              const half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + sv * 8);
+              half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + sv * 8);
+              if (p.res && p.res_late) {   // residual added on the way out (coalesced 16-byte reads, no staging pass / barrier)
+                const half8 rv = ldg_half8(p.res + (size_t)m * p.ldres + n);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[j] = (half_t)((float)val[j] + (float)rv[j]);
+              }
               *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = val;
               if (p.stats) {
 #pragma unroll
@@ -725,7 +776,7 @@ void gemm_defaults(GemmP& p) {
   p.B = 1; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.ksize = 1; p.stride = 1; p.pad = 0; p.ups = 0;
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
   p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1;
-  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr;
+  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr; p.res_late = 0;
 }
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
@@ -734,6 +785,9 @@ static half_t* g_zero_page = nullptr;
 static constexpr size_t ZERO_PAGE_BYTES = 128 << 10;   // >= 2 * (longest K + one chunk): out-of-range rows walk it like real rows
 static int g_wide = 1;      // PNPI_IGEMM_WIDE=0: never pick the 128x320 / 128x256 tiles (ablation)
 static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
+static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in the store loop (fp16(fp16(acc + bias) + res)) instead of staged
+static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
+static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
 static int g_force_cfg = -1;   // >= 0: every auto-configured launch uses this tile configuration (tests, whole-forward A/B)
 static int g_var128 = 2, g_var64 = 0, g_var256 = 0, g_var320 = 1, g_var256n = 1;
 static long g_v128_bk64_tiles = 0;   // PNPI_V128_BK64_TILES: tile count from which the 128x128 kernel switches to 128-byte rows   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
@@ -741,7 +795,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -819,6 +873,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
         const double resid = 0.835 + 0.165 * fill;
         double t = (double)on_busiest * unit / resid;
         if (s > 1) t += (double)(2 * s + 1) * p.M * p.N * 4.0 / 8.77e12 + 4.94e-6;   // slabs written, re-read, output + the reduce launch
+        if (p.vt_col0 < p.N && p.vt_col0 % tc.bn != 0) t *= 1.3;   // transposed columns not tile-aligned: scalar epilogue
         if (t < best) { best = t; cfg = tc.id; split = s; }
       }
     }
@@ -840,7 +895,15 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (cfg_used) *cfg_used = split > 1 ? 2 : (cfg >= 4 ? 9 : (cfg == 1 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
-  p.epi_lds = (p.vt_col0 >= p.N) && (p.N % 8 == 0) && (p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
+  const int bn_sel = (cfg == 4 || cfg == 6) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (cfg == 1 ? 64 : 128));
+  const bool vt_none = p.vt_col0 >= p.N;
+  // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay
+  // inside one batch item
+  const bool vt_lds = !vt_none && dma_ok && p.outT && !p.vt_f32 && p.vt_col0 % bn_sel == 0 && p.rows_per_batch % 8 == 0 && p.vt_ld % 8 == 0 &&
+                      p.M % 8 == 0 && !p.res && !p.geglu && g_vt_lds;
+  p.epi_lds = (vt_none || vt_lds) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
+  if (vt_lds) p.stats = nullptr;
+  p.res_late = g_res_late;
   if (p.geglu && !(p.epi_lds && dma_ok && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
   const int bm = (cfg == 3 || cfg >= 6) ? 256 : (cfg == 1 ? 64 : 128);
@@ -849,6 +912,11 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.slab = ws;
   dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, split);
   int r = 0;
+  // Ring depth by occupancy: with at most one block per CU nothing else covers the HBM latency of the weight stream (cold in a
+  // forward: 1.7 GB of weights pass through per UNet call), and the whole 160 KB of LDS is free -- so sparse launches take an
+  // 8-deep ring (7 chunks in flight per block); two blocks per CU a 4-deep one; fuller launches the shallow rings that fit 3 blocks.
+  const long units = (long)grid.x * grid.y * grid.z;
+  const int sparse = !g_deep_rings ? 0 : (units <= 256 ? 2 : (units <= 512 ? 1 : 0));
   if (!dma_ok) {
     if (cfg == 1) {
       if (fast) igemm_kernel<64, 64, true><<<grid, 256, lds_bytes(64, 64), st>>>(p);
@@ -860,7 +928,8 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (cfg == 3) {
     r = g_var256 == 1 ? launch_dma<256, 128, 32, 2, 2>(p, grid, st, g_zero_page) : launch_dma<256, 128, 32, 3, 2>(p, grid, st, g_zero_page);
   } else if (cfg == 4) {
-    switch (g_var320) {
+    if (sparse == 2 && g_var320 == 1) r = launch_dma<128, 320, 32, 5>(p, grid, st, g_zero_page);
+    else switch (g_var320) {
       case 0: r = launch_dma<128, 320, 32, 3>(p, grid, st, g_zero_page); break;       // 84 KB ring = whole-tile epilogue, 1 block / CU
       case 2: r = launch_dma<128, 320, 64, 2>(p, grid, st, g_zero_page); break;       // 128-byte rows, 112 KB, 1 block / CU
       case 11: r = launch_dma<128, 320, 32, 2, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
@@ -872,7 +941,8 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (cfg == 7) {
     r = launch_dma<256, 256, 64, 2, 4>(p, grid, st, g_zero_page);
   } else if (cfg == 5) {
-    switch (g_var256n) {
+    if (sparse == 2 && g_var256n == 1) r = launch_dma<128, 256, 32, 6>(p, grid, st, g_zero_page);
+    else switch (g_var256n) {
       case 0: r = launch_dma<128, 256, 32, 3>(p, grid, st, g_zero_page); break;       // 72 KB, 2 blocks / CU
       case 2: r = launch_dma<128, 256, 64, 2>(p, grid, st, g_zero_page); break;
       default: r = launch_dma<128, 256, 32, 2>(p, grid, st, g_zero_page); break;      // 48 KB: two-pass epilogue, 3 blocks / CU by LDS
@@ -882,18 +952,25 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     // 128-byte rows with 2 stages (64 KB, 2 blocks / CU) beat 64-byte rows with 3 stages (48 KB, 3 blocks / CU) once every CU
     // holds two blocks that cover for each other's exposed loads; below that the deeper ring wins
     if (g_v128_bk64_tiles > 0 && var == 2 && (long)grid.x * grid.y * grid.z >= g_v128_bk64_tiles) var = 0;
+    if (var == 2 && sparse == 2) var = 8;
+    else if (var == 2 && sparse == 1) var = 3;
     switch (var) {
       case 1: r = launch_dma<128, 128, 64, 3>(p, grid, st, g_zero_page); break;
       case 2: r = launch_dma<128, 128, 32, 3>(p, grid, st, g_zero_page); break;
       case 3: r = launch_dma<128, 128, 32, 4>(p, grid, st, g_zero_page); break;
       case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
+      case 8: r = launch_dma<128, 128, 32, 8>(p, grid, st, g_zero_page); break;       // 128 KB ring: sparse launches
       case 11: r = launch_dma<128, 128, 32, 3, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
       case 12: r = launch_dma<128, 128, 32, 3, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
       case 15: r = launch_dma<128, 128, 32, 3, 2, 3>(p, grid, st, g_zero_page); break;   // ablation: activation loads for tap 0 only
       default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;
     }
   } else {
-    switch (g_var64) {
+    int v64 = g_var64;
+    if (v64 == 0 && sparse == 2) v64 = 8;
+    else if (v64 == 0 && sparse == 1) v64 = 2;
+    switch (v64) {
+      case 8: r = launch_dma<64, 64, 64, 8>(p, grid, st, g_zero_page); break;         // 128 KB ring: sparse launches
       case 1: r = launch_dma<64, 64, 64, 2>(p, grid, st, g_zero_page); break;
       case 2: r = launch_dma<64, 64, 64, 4>(p, grid, st, g_zero_page); break;
       case 3: r = launch_dma<64, 64, 32, 4>(p, grid, st, g_zero_page); break;

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) gn_fin_apply_kernel(const half_t* __restr
   }
 }
 
-static int g_gn_inline_rows = 1 << 20;   // statistics-fused GroupNorm: one launch (finalize inside apply) up to this many B*HW rows
+static int g_gn_inline_rows = 0;   // statistics-fused GroupNorm: one launch (finalize inside apply) up to this many B*HW rows
 void norm_set_tuning_gn_inline_rows(int v) { g_gn_inline_rows = v; }
 
 int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,

@@ -26,6 +26,7 @@ struct GemmP {
   float* stats;   // optional: per (m-tile, channel) sum / sum-of-squares of the fp16 output, [gridDim.x][N][2] (GroupNorm fusion)
   int geglu;      // N columns are [x(32) | gate(32)] interleaved groups; output has N/2 columns: x * gelu(gate)
   int epi_lds;    // set by launch_igemm: coalesced LDS-staged epilogue is applicable
+  int res_late;   // set by launch_igemm: the LDS epilogue adds the residual in its store loop instead of staging it
   int gx, gy, gz, tile_order;   // set by the launcher: logical tile grid and XCD-aware traversal order (see igemm_dma_kernel)
 };
 void gemm_defaults(GemmP& p);
@@ -116,7 +117,8 @@ int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to,
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale,
                          float a_t, float a_prev, const float* noise_loss, int offset_rows, const float* target,
                          float offset_scale, float* offset_out, float* x_out, hipStream_t st, const float* prox_thr = nullptr,
-                         int prox_mode = 0);
+                         int prox_mode = 0, const float* recon_ref = nullptr, float recon_lr = 0.f, int dilate = 0, int lat_h = 0,
+                         int lat_w = 0);   // recon_ref [nimg][row_elems]: reconstruction guidance (needs prox_mode)
 // threshold of the proximal-guidance step: quantile q of |eps_c - eps_u| over the rows of each image (torch.quantile, linear)
 int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_t row_elems, float q, float* thr_out, hipStream_t st);
 int launch_fill_f32(float* p, int n, float v, hipStream_t st);

@@ -37,37 +37,66 @@ int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to,
   return (int)hipGetLastError();
 }
 
+// proximal guidance (proximal_guidance_forward.py:39-62): score_delta -= clamp(score_delta, -thr, thr); 'l1' then shrinks the
+// survivors by thr once more on each side
+__device__ __forceinline__ float prox_shrink(float d, float th, int mode) {
+  d = __fsub_rn(d, fminf(fmaxf(d, -th), th));
+  if (mode == 2) {
+    if (d > 0.f) d = __fsub_rn(d, th);
+    if (d < 0.f) d = __fadd_rn(d, th);
+  }
+  return d;
+}
+
 // eps: [nimg][2R][E] (first R rows unconditional, next R conditional); x: [nimg][R][E]
 //   e   = eps_u + g * (eps_c - eps_u)
 //   prev = ddim(x, e)
 //   target != null  (offset_calculate):  loss = (target[img] - prev) * oscale ; offset_out = loss ; x_out = prev + loss
 //   else noise_loss != null            :  x_out = prev + noise_loss[img][r]  for r < offset_rows, prev otherwise
+// recon_ref != null (reconstruction guidance, proximal_guidance_forward.py:48-51,60-72 + DDIMSchedulerDev.step scheduler_dev.py:68-76):
+//   mask_edit = |shrunk delta| > thr, dilated by a (2*dil+1)^2 max-pool over each [h][w] plane (in-bounds neighbours only);
+//   pred_x0 -= recon_lr * (pred_x0 - ref[img]) * (1 - mask_edit)   before the step's second half
 __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float* __restrict__ x, int nimg, int R, size_t E, float g,
                                      float sa_f, float sb_f, float sa_t, float sb_t, const float* __restrict__ noise_loss,
                                      int offset_rows, const float* __restrict__ target, float oscale,
                                      float* __restrict__ offset_out, float* __restrict__ x_out, const float* __restrict__ prox_thr,
-                                     int prox_mode) {
+                                     int prox_mode, const float* __restrict__ recon_ref, float recon_lr, int dil, int lat_h, int lat_w) {
   const size_t total = (size_t)nimg * R * E;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t e_idx = i % E;
     size_t ir = i / E;
     int r = (int)(ir % R);
     int img = (int)(ir / R);
-    float eu = eps[((size_t)img * 2 * R + r) * E + e_idx];
-    float ec = eps[((size_t)img * 2 * R + R + r) * E + e_idx];
+    const float* eu_row = eps + ((size_t)img * 2 * R + r) * E;
+    const float* ec_row = eps + ((size_t)img * 2 * R + R + r) * E;
+    float eu = eu_row[e_idx];
+    float ec = ec_row[e_idx];
     float d = __fsub_rn(ec, eu);
-    if (prox_mode) {
-      // proximal guidance (proximal_guidance_forward.py:39-62): score_delta -= clamp(score_delta, -thr, thr); 'l1' then shrinks
-      // the survivors by thr once more on each side
-      const float th = prox_thr[img];
-      d = __fsub_rn(d, fminf(fmaxf(d, -th), th));
-      if (prox_mode == 2) {
-        if (d > 0.f) d = __fsub_rn(d, th);
-        if (d < 0.f) d = __fadd_rn(d, th);
-      }
-    }
+    const float th = prox_mode ? prox_thr[img] : 0.f;
+    if (prox_mode) d = prox_shrink(d, th, prox_mode);
     float e = __fadd_rn(eu, __fmul_rn(g, d));
-    float prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
+    float prev;
+    if (recon_ref && prox_mode) {
+      float mask_edit = fabsf(d) > th ? 1.f : 0.f;
+      if (dil > 0 && mask_edit == 0.f) {
+        const int hw = lat_h * lat_w;
+        const int pl = (int)(e_idx / hw), py = (int)(e_idx % hw) / lat_w, px = (int)(e_idx % hw) % lat_w;
+        for (int dy = -dil; dy <= dil && mask_edit == 0.f; ++dy)
+          for (int dx = -dil; dx <= dil; ++dx) {
+            const int yy = py + dy, xx = px + dx;
+            if (yy < 0 || yy >= lat_h || xx < 0 || xx >= lat_w) continue;
+            const size_t j = (size_t)pl * hw + (size_t)yy * lat_w + xx;
+            const float dn = prox_shrink(__fsub_rn(ec_row[j], eu_row[j]), th, prox_mode);
+            if (fabsf(dn) > th) { mask_edit = 1.f; break; }
+          }
+      }
+      const float recon_mask = __fsub_rn(1.f, mask_edit);
+      float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(sb_f, e)), sa_f);
+      x0 = __fsub_rn(x0, __fmul_rn(__fmul_rn(recon_lr, __fsub_rn(x0, recon_ref[(size_t)img * E + e_idx])), recon_mask));
+      prev = __fadd_rn(__fmul_rn(sa_t, x0), __fmul_rn(sb_t, e));
+    } else {
+      prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
+    }
     float outv = prev;
     if (target) {
       // loss = (x*_{t-1} - prev) * scale: scale is 1 on the paper's path, `scale` / 0-or-1 in the not_full / skip_step ablations
@@ -84,14 +113,17 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
 
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale, float a_t,
                          float a_prev, const float* noise_loss, int offset_rows, const float* target, float offset_scale,
-                         float* offset_out, float* x_out, hipStream_t st, const float* prox_thr, int prox_mode) {
+                         float* offset_out, float* x_out, hipStream_t st, const float* prox_thr, int prox_mode, const float* recon_ref,
+                         float recon_lr, int dilate, int lat_h, int lat_w) {
   float sa_f = sqrtf(a_t), sb_f = sqrtf(1.0f - a_t), sa_t = sqrtf(a_prev), sb_t = sqrtf(1.0f - a_prev);
   size_t total = (size_t)nimg * rows_per_img * row_elems;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
+  if (recon_ref && (lat_h <= 0 || lat_w <= 0 || row_elems % ((size_t)lat_h * lat_w))) return -3;
   cfg_ddim_prev_kernel<<<blocks, 256, 0, st>>>(eps, x, nimg, rows_per_img, row_elems, gscale, sa_f, sb_f, sa_t, sb_t, noise_loss,
-                                               offset_rows, target, offset_scale, offset_out, x_out, prox_thr, prox_mode);
+                                               offset_rows, target, offset_scale, offset_out, x_out, prox_thr, prox_mode, recon_ref,
+                                               recon_lr, dilate, lat_h, lat_w);
   return (int)hipGetLastError();
 }
 

@@ -339,7 +339,10 @@ class NativeEngine:
         self._keep = (lat, ctx, ts, arr, flat, sc)
         return nl, out
 
-    def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1, prox=None, quantile=0.7):
+    def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1, prox=None, quantile=0.7,
+                  recon=None):
+        """recon: None | dict(ref_image=[nimg,4,h,w] encoded source latent, recon_lr, recon_t, dilate_mask): reconstruction guidance
+        (proximal_guidance_forward.py:48-51 + scheduler_dev.py:68-76), applied with prox 'l0' / 'l1' only."""
         xT, ctx = self._f32(x_T), self._f32(context4)
         nl = self._f32(noise_loss) if noise_loss is not None else None
         n = len(timesteps)
@@ -348,7 +351,11 @@ class NativeEngine:
         ts, tsp = self._ts(timesteps)
         arr = _desc_array(ctrls)
         mode = {None: 0, "l0": 1, "l1": 2}[prox]
+        rd, ref = None, None
+        if recon is not None:
+            ref = self._f32(recon["ref_image"]).reshape(nimg, *xT.shape[1:]).contiguous()
+            rd = _capi.ReconDesc(ref.data_ptr(), float(recon["recon_lr"]), int(recon["recon_t"]), int(recon.get("dilate_mask") or 0))
         self._call("pnpi_edit_loop", _p(xT), nimg, _p(ctx), _p(nl), int(offset_rows), arr, n, tsp, float(guidance_scale), mode,
-                   float(quantile), _p(out))
-        self._keep = (xT, ctx, nl, ts, arr, ctrls)
+                   float(quantile), C.byref(rd) if rd is not None else None, _p(out))
+        self._keep = (xT, ctx, nl, ts, arr, ctrls, ref, rd)
         return out

@@ -63,7 +63,7 @@ def _constant_uncond(uncond_embeddings):
 
 @torch.no_grad()
 def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 50, guidance_scale=7.5, generator=None, latent=None,
-                         uncond_embeddings=None, prox=None, quantile=0.7):
+                         uncond_embeddings=None, prox=None, quantile=0.7, recon=None):
     """models/p2p/p2p_guidance_forward.py:21-62: the plain Prompt-to-Prompt CFG loop (no direct-inversion offset); one or two
     prompts; `uncond_embeddings` = per-step replacement of the "" embedding."""
     batch_size = len(prompt)
@@ -88,7 +88,7 @@ def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 5
     if prox is not None and batch_size != 2:
         raise NotImplementedError("the proximal step takes its quantile over the (source, target) pair")
     out = model.engine.edit_loop(latent.reshape(1, *latent.shape[-3:]), context[None], None, [tables] if tables is not None else None,
-                                 model.scheduler.timesteps.numpy(), guidance_scale, prox=prox, quantile=quantile)
+                                 model.scheduler.timesteps.numpy(), guidance_scale, prox=prox, quantile=quantile, recon=recon)
     if controller is not None and hasattr(controller, "cur_step"):
         controller.cur_step += num_inference_steps
     return out[0][:batch_size], latent

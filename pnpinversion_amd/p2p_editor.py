@@ -214,17 +214,16 @@ class P2PEditor:
                                              return_stages=False):
         """models/p2p_editor.py:324-413: the source prompt's embedding replaces "" in the unconditional rows; with proximal
         "l0" / "l1" the edit pass soft-thresholds the CFG difference (proximal_guidance_forward.py:39-64)."""
-        if use_reconstruction_guidance:
-            raise NotImplementedError("reconstruction guidance is not built (SURVEY 8f rank 3)")
         image_gt, side = self._load(image_path)
         self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
         inv = NegativePromptInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
-        _, _, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, npi_interp=npi_interp)
-        def fwd(**k):   # reconstruction: edit_stage=False (no proximal step); edit: the method's prox / quantile
+        _, image_enc_latent, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, npi_interp=npi_interp)
+        on = use_reconstruction_guidance or use_inversion_guidance
+        def fwd(**k):   # reconstruction: edit_stage=False (no proximal step); edit: the method's prox / quantile (p2p_editor.py:389-405)
             edit = len(k["prompt"]) == 2
             return proximal_guidance_forward(edit_stage=edit, prox=proximal if edit else None, quantile=quantile,
-                                             recon_lr=recon_lr if use_inversion_guidance else 0,
-                                             recon_t=recon_t if use_inversion_guidance else 1000, dilate_mask=dilate_mask,
+                                             image_enc=image_enc_latent if (edit and use_reconstruction_guidance) else None,
+                                             recon_lr=recon_lr if on else 0, recon_t=recon_t if on else 1000, dilate_mask=dilate_mask,
                                              num_inference_steps=self.num_ddim_steps, **k)
         return self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                                self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)

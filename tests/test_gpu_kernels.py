@@ -130,6 +130,29 @@ def test_gemm_transposed_region(ctx):
     assert rel_err(o32, ref.reshape(Bn, T, N).permute(0, 2, 1)) < 1e-5
 
 
+@pytest.mark.parametrize("cfg,col0,N,T,vt_lds", [(0, 256, 384, 64, 1), (1, 128, 192, 256, 1), (5, 512, 768, 1024, 1), (4, 640, 960, 64, 1),
+                                                  (0, 256, 384, 64, 0), (4, 512, 768, 256, 1)])
+def test_gemm_transposed_columns_through_lds_epilogue(ctx, cfg, col0, N, T, vt_lds):
+    """Fused q|k|v projection: columns >= col0 leave TRANSPOSED per batch item (V^T for the attention kernel).  With tile-aligned
+    col0 the LDS epilogue stages those tiles transposed and stores 8-token runs (tokens per item below, equal to and above the tile
+    height); (4, 512, ...) is the misaligned case that falls back to the scalar epilogue; vt_lds = 0 forces that fallback."""
+    Bn, K = 3, 320
+    M = Bn * T
+    a, w = h16(M, K, seed=61), h16(N, K, scale=1.0 / math.sqrt(K), seed=62)
+    bias = torch.randn(N, device=DEV)
+    out = torch.zeros(M, col0, dtype=torch.half, device=DEV)
+    vt = torch.zeros(Bn, N - col0, T, dtype=torch.half, device=DEV)
+    assert ctx.lib.pnpi_set_tuning(b"igemm_vt_lds", vt_lds) == 0
+    try:
+        ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, 1.0, ptr(bias), None, ptr(out), col0, col0, ptr(vt), T, 0, T, cfg, 0)
+        torch.cuda.synchronize()
+    finally:
+        ctx.lib.pnpi_set_tuning(b"igemm_vt_lds", 1)
+    ref = a.float() @ w.float().t() + bias
+    assert rel_err(out, ref[:, :col0]) < 2e-3
+    assert rel_err(vt, ref[:, col0:].reshape(Bn, T, N - col0).permute(0, 2, 1)) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------ conv
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
@@ -408,13 +431,13 @@ def test_step_kernels_bit_exact(ctx):
         off = torch.empty(2, 4, 16, 16, device=DEV)
         xo = torch.empty(2, 4, 16, 16, device=DEV)
         td = target.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), 1.0, ptr(off), ptr(xo), None, 0)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, None, 0, ptr(td), 1.0, ptr(off), ptr(xo), None, 0, None)
         assert torch.equal(off.cpu(), loss) and torch.equal(xo.cpu(), cur), t
         # guidance step with noise_loss on the first row only (p2p_guidance_forward.py:110-114)
         nl = torch.randn(2, 4, 16, 16, generator=g)
         ref2 = torch.cat((prev[:1] + nl[:1], prev[1:]))
         nld = nl.to(DEV)
-        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, 1.0, None, ptr(xo), None, 0)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(e4d), ptr(xd), 1, 2, x[0].numel(), 7.5, t, 20, ptr(nld), 1, None, 1.0, None, ptr(xo), None, 0, None)
         assert torch.equal(xo.cpu(), ref2), t
         # DDIMSchedulerDev.step == prev_step
         ctx.call("pnpi_ddim_prev_step", ptr(ed), t, 20, ptr(xd), x.numel(), ptr(out))
@@ -460,7 +483,7 @@ def test_proximal_step_bit_exact(ctx, prox):
         thr = d.abs().quantile(q)
         assert torch.equal(thr_d.cpu()[0], thr), (q, thr_d.item(), thr.item())
         ctx.call("pnpi_cfg_ddim_prev", ptr(ed), ptr(xd), 1, 2, x[0].numel(), 7.5, t, ratio, None, 0, None, 1.0, None, ptr(xo),
-                 ptr(thr_d), 1 if prox == "l0" else 2)
+                 ptr(thr_d), 1 if prox == "l0" else 2, None)
         sd = d - d.clamp(-thr, thr)
         if prox == "l1":
             sd = torch.where(sd > 0, sd - thr, sd)
@@ -469,3 +492,46 @@ def test_proximal_step_bit_exact(ctx, prox):
         a_t, a_p = po.prev_alphas(ac, ac[0], t, ratio)
         want = po.ddim_move(x, e, float(a_t), float(a_p))
         assert torch.equal(xo.cpu(), want), (xo.cpu() - want).abs().max()
+
+
+@pytest.mark.parametrize("dil", [0, 1, 2])
+@pytest.mark.parametrize("prox", ["l0", "l1"])
+def test_reconstruction_guidance_step_bit_exact(ctx, prox, dil):
+    """Reconstruction guidance (proximal_guidance_forward.py:48-51,60-72 + DDIMSchedulerDev.step's ref_image branch,
+    scheduler_dev.py:68-76) inside the CFG / DDIM-step kernel: mask_edit = dilate(|shrunk delta| > thr), pred_x0 pulled towards the
+    encoded source image where the mask is off -- bit for bit against the reference's formulas; inert outside the recon_t window."""
+    from oracle import p2p_oracle as po
+    from pnpinversion_amd import _capi
+    g = torch.Generator().manual_seed(12)
+    eps = torch.randn(4, 4, 64, 64, generator=g)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    ref = torch.randn(1, 4, 64, 64, generator=g)
+    ac, ratio, lr = po.alphas_cumprod(), 20, 0.1
+    ctx.call("pnpi_set_scheduler", (C.c_float * 1000)(*ac.tolist()), 1000, float(ac[0]))
+    ed, xd, rd = eps.cuda(), x.cuda(), ref.cuda()
+    thr_d = torch.empty(1, device="cuda")
+    ctx.call("pnpi_prox_threshold", ptr(ed), 1, 2, x[0].numel(), 0.75, ptr(thr_d))
+    thr = thr_d.cpu()[0]
+    d = eps[2:] - eps[:2]
+    sd = d - d.clamp(-thr, thr)
+    if prox == "l1":
+        sd = torch.where(sd > 0, sd - thr, sd)
+        sd = torch.where(sd < 0, sd + thr, sd)
+    e = eps[:2] + 7.5 * sd
+    mask_edit = (sd.abs() > thr).float()
+    if dil > 0:
+        mask_edit = F.max_pool2d(mask_edit, 2 * dil + 1, 1, dil)
+    recon_mask = 1 - mask_edit
+    desc = _capi.ReconDesc(rd.data_ptr(), lr, 400, dil)
+    for t, active in ((381, True), (401, False)):
+        xo = torch.empty_like(xd)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(ed), ptr(xd), 1, 2, x[0].numel(), 7.5, t, ratio, None, 0, None, 1.0, None, ptr(xo),
+                 ptr(thr_d), 1 if prox == "l0" else 2, C.byref(desc))
+        a_t, a_p = po.prev_alphas(ac, ac[0], t, ratio)
+        sa_f, sb_f, sa_t, sb_t = po._scalars(float(a_t), float(a_p), torch.float32)
+        x0 = (x - sb_f * e) / sa_f
+        if active:
+            x0 = x0 - lr * (x0 - ref.expand_as(x0)) * recon_mask
+        want = sa_t * x0 + sb_t * e
+        assert torch.equal(xo.cpu(), want), (t, (xo.cpu() - want).abs().max())
+    assert 0.05 < recon_mask.mean().item() < 0.95

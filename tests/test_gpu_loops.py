@@ -381,6 +381,34 @@ def test_proximal_guidance_against_reference_golden(small64, prox):
     assert rel(st["latents"], v[other + "/edited_latents"]) > 3 * r                        # and not the other variant
 
 
+@pytest.mark.parametrize("prox", ["l0", "l1"])
+def test_reconstruction_guidance_against_reference_golden(small64, prox):
+    """"negative-prompt-inversion+proximal-guidance" with use_reconstruction_guidance=True: the reference's own P2PEditor run
+    (tests/golden/e2e_proximal_recon.npz; 4 steps, the masked pred-x0 pull active at t = 250 and t = 0, dilate_mask = 1)."""
+    v = np.load(os.path.join(GOLD, "e2e_proximal_recon.npz"))
+    steps = int(v["steps"])
+    ed = P2PEditor(["negative-prompt-inversion+proximal-guidance"], "cuda", num_ddim_steps=steps, pipeline=small64)
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    w0, w1 = [str(x) for x in v["blend"]]
+    kw = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+              eq_params={"words": (w1,), "values": (2,)}, proximal=prox, quantile=0.75, recon_lr=float(v["recon_lr"]),
+              recon_t=int(v["recon_t"]), dilate_mask=int(v["dilate_mask"]))
+    panel = ed("negative-prompt-inversion+proximal-guidance", img, str(v["src"]), str(v["tgt"]), use_reconstruction_guidance=True, **kw)
+    small = np.array(panel)[::4, 1536::4]
+    assert np.abs(small.astype(np.int32) - v[prox + "/edited_image_small"].astype(np.int32)).mean() < 4.0
+    _, st = ed.edit_image_negative_prompt_inversion(img, str(v["src"]), str(v["tgt"]), use_reconstruction_guidance=True,
+                                                    return_stages=True, **kw)
+    # hard per-element decisions (shrink, edit mask) within fp16 noise of the threshold fall on the other side for a few pixels
+    r, frac = masked_rel(st["latents"], torch.from_numpy(v[prox + "/edited_latents"]), tol_frac=0.03)
+    assert frac <= 0.03 and r < 2.5e-2, (prox, r, frac)
+    # and it is not the run without the pull
+    _, st0 = ed.edit_image_negative_prompt_inversion(img, str(v["src"]), str(v["tgt"]), use_reconstruction_guidance=False,
+                                                     return_stages=True, **kw)
+    assert rel(st0["latents"], v[prox + "/edited_latents"]) > 3 * r
+    small64.scheduler.set_timesteps(2)
+
+
 def test_masactrl_driver_cli(tmp_path, capsys):
     """run_editing_masactrl.py end to end (both methods, native CLIP text encoder) on a 2-image PIE-Bench-shaped directory."""
     import json

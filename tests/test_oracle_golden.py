@@ -14,7 +14,7 @@ from oracle import sd_oracle
 from pnpinversion_amd import weights
 from pnpinversion_amd.config import SD1, SMALL64, TINY16
 from pnpinversion_amd.p2p import attention_control as ac
-from pnpinversion_amd.text import WordTokenizer
+from pnpinversion_amd.text import SyntheticTextEncoder, WordTokenizer
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -222,6 +222,36 @@ def test_proximal_guidance_matches_reference():
     out = po.guidance_forward(unet_fn, x_T, c4, None, ctrl, ts, ac_, ac_[0], 7.5, prox="l0", quantile=0.75)
     assert rel(out, v["l0/edited_latents"]) < 5e-5, rel(out, v["l0/edited_latents"])
     assert rel(torch.from_numpy(v["l1/edited_latents"]), v["l0/edited_latents"]) > 1e-3      # the two variants differ
+
+
+def test_reconstruction_guidance_matches_reference():
+    """The same method with use_reconstruction_guidance=True (tests/golden/e2e_proximal_recon.npz: 4 steps, recon_t 400, recon_lr 0.5,
+    dilate_mask 1): the oracle's masked pred-x0 pull + dilated edit mask against the reference's own run."""
+    v = load("e2e_proximal_recon.npz")
+    cfg, steps = SMALL64, int(v["steps"])
+    usd = weights.unet_state_dict(cfg, 2)
+    ctx = torch.from_numpy(v["context"]).float()                    # NegativePromptInversion.context = [unc, cond] of the source prompt
+    ac_, ts = po.alphas_cumprod(), po.make_timesteps(steps)
+
+    def unet_fn(lat, t, c, hook):
+        with torch.no_grad():
+            return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    x_stars = torch.from_numpy(v["x_stars"])
+    enc = SyntheticTextEncoder(cfg.cross_dim, seed=7)
+    tok = WordTokenizer()
+    tgt_emb = enc(tok([str(v["tgt"])], padding="max_length", max_length=77).input_ids)[0].float()
+    c4 = torch.cat([ctx[1:2], ctx[1:2], ctx[1:2], tgt_emb])         # cond_src replaces "" in both unconditional rows
+    g = {"src": v["src"], "tgt": v["tgt"], "blend": v["blend"], "use_blend": True, "is_replace": False}
+    recon = {"ref_image": torch.from_numpy(v["image_enc_latent"]), "recon_lr": float(v["recon_lr"]), "recon_t": int(v["recon_t"]),
+             "dilate_mask": int(v["dilate_mask"])}
+    for prox in ("l0", "l1"):
+        ctrl = po.EditController(32, _tables_from_product(g, steps))
+        out = po.guidance_forward(unet_fn, x_stars[-1], c4, None, ctrl, ts, ac_, ac_[0], 7.5, prox=prox, quantile=0.75, recon=recon)
+        assert rel(out, v[prox + "/edited_latents"]) < 5e-5, (prox, rel(out, v[prox + "/edited_latents"]))
+    plain = po.guidance_forward(unet_fn, x_stars[-1], c4, None, po.EditController(32, _tables_from_product(g, steps)), ts, ac_, ac_[0], 7.5,
+                                prox="l0", quantile=0.75)
+    assert rel(plain, v["l0/edited_latents"]) > 1e-3                # the pull matters
 
 
 @pytest.mark.parametrize("name,cfg", [("tiny", TINY16), ("sd1", SD1)])
