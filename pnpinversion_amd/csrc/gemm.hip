@@ -322,9 +322,16 @@ static int g_tile_order = -1;   // PNPI_TILE_ORDER: force 0 / 1 (ablation)
 // Tile geometry: WGM x 2 wavefronts (NT = 128 * WGM threads); a wave owns (BM / WGM) x (BN / 2) of the block tile as 32x32 MFMA
 // tiles.  Instantiated shapes (BM x BN, wave tile): 64x64 (32x32), 128x128 (64x64), 128x256 (64x128), 128x320 (64x160: 20
 // MFMAs per 32-deep k-chunk and barrier, 91 FLOP per operand byte -- the N = 320 / 640 / 1280 layers tile exactly), 256x128.
-template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0>
+//
+// WK > 1: K-parallel wave groups.  The block holds WK groups of WGM x 2 waves; group g owns its own LDS ring and walks the g-th
+// contiguous slice of the block's k-range into its own accumulators (the groups run in lock step on the one workgroup barrier per
+// chunk), then groups 1 .. WK-1 hand their fp32 accumulators to group 0 through LDS in a FIXED order and exit; group 0 runs the
+// epilogue.  A launch with at most one tile per CU (the one-row inversion forwards, the 16 x 16 / 8 x 8 levels) puts WK times the
+// MFMA-issuing waves on every CU this way -- split-K with the partial sums in LDS instead of slabs + a reduce launch.
+template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
 struct IgemmGeom {
-  static constexpr int NW = 2 * WGM, NT = 64 * NW;
+  static constexpr int NW = 2 * WGM, NT = 64 * NW;              // waves / threads of ONE k-group (= the epilogue's threads)
+  static constexpr int NT_ALL = NT * WK;
   static constexpr int WM = BM / WGM, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   static constexpr int RPI = 1024 / (BKT * 2);                 // tile rows per 1-KiB DMA instruction (8 or 16)
   static constexpr int AV = BM / RPI / NW, WV = BN / RPI / NW;  // DMA instructions per wave per chunk and operand
@@ -340,23 +347,28 @@ struct IgemmGeom {
   static constexpr int TOLD = EROWS + 8;                        // halfs per staged row of a TRANSPOSED tile ([BN][EROWS + 8])
   static constexpr int EPI_PLAIN = EROWS * OLD * 2 + STATS_B, EPI_TR = BN * TOLD * 2;
   static constexpr int EPI = EPI_PLAIN > EPI_TR ? EPI_PLAIN : EPI_TR;
-  static constexpr int LDS = RING > EPI ? RING : EPI;
+  static constexpr int RED = (WK - 1) * BM * BN * 4;            // fp32 accumulators of groups 1 .. WK-1 on their way to group 0
+  static constexpr int LDS0 = WK * RING > EPI ? WK * RING : EPI;
+  static constexpr int LDS = LDS0 > RED ? LDS0 : RED;
+  static_assert(LDS <= 160 * 1024, "LDS");
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "DMA instructions must divide evenly over the waves");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % 64 == 0, "wave tile");
 };
 
-template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0>
-__global__ void __launch_bounds__(128 * WGM, (IgemmGeom<BM, BN, BKT, NST, WGM>::LDS * 2 <= 160 * 1024 && BN <= 320) ? (2 * 2 * WGM / 4) : (2 * WGM / 4))
+template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
+__global__ void __launch_bounds__(128 * WGM * WK, (IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>::LDS * 2 <= 160 * 1024 && BN <= 320 && WK == 1) ? (2 * 2 * WGM / 4) : (2 * WGM * WK / 4))
 igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   static_assert(BKT == 64 || BKT == 32, "BKT");
-  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM>;
+  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>;
   constexpr int NT = GEO::NT, NW = GEO::NW;
   constexpr int WM = GEO::WM, WN = GEO::WN, MI = GEO::MI, NI = GEO::NI;
   constexpr int AV = GEO::AV, WV = GEO::WV, ROWB = GEO::ROWB, STAGE = GEO::STAGE;
   constexpr int T32 = 32 * ROWB;                       // bytes per 32-row MFMA tile
-  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+  extern __shared__ __attribute__((aligned(1024))) char smem_all[];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & (NT - 1), lane = tid & 63;                    // thread / wave index inside the k-group
+  const int kgrp = WK == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
+  char* smem_raw = smem_all + kgrp * GEO::RING;                                 // this group's ring
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   // XCD-aware tile order.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with a private L2), so the
@@ -414,6 +426,12 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   if (p.splitk > 1) {   // kchunks_per_split is given in 64-wide chunks
     kc0 = bz * p.kchunks_per_split * (64 / BKT);
     kc1 = min(nchunks, kc0 + p.kchunks_per_split * (64 / BKT));
+  }
+  int iters = kc1 > kc0 ? kc1 - kc0 : 0;      // loop trips: the same for every k-group (they share the barrier)
+  if (WK > 1) {
+    iters = (iters + WK - 1) / WK;
+    kc0 = min(kc1, kc0 + kgrp * iters);
+    kc1 = min(kc1, kc0 + iters);
   }
   // Weight rows: one pointer per DMA instruction, bumped by BKT per chunk.  Rows past N read the zero page, which is as long
   // as the longest K this kernel is launched with, so they are bumped like the others (no select in the loop).
@@ -493,14 +511,14 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   // counted vmcnt (the newer chunks stay in flight across the barrier), then one raw barrier per chunk makes every wave's
   // part of chunk k visible and, at the same time, frees the stage that was read in the previous iteration.
   constexpr int LPS = AV + WV;   // DMA instructions per wave per chunk
-  if (kc0 < kc1) {
-    const int total = kc1 - kc0;
+  if (iters > 0) {
+    const int total = kc1 - kc0;   // this group's chunks (<= iters; a short last group idles through its tail but keeps the barrier)
     int issued = 0;
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
       if (issued < total) { if (ABL != 2) issue(st); ++issued; }
     int rd = 0, wr = NST - 1;
-    for (int it = 0; it < total; ++it) {
+    for (int it = 0; it < iters; ++it) {
       const int ahead = issued - it - 1;           // chunks issued after the one needed now (0 .. NST-2)
       static_assert((NST - 2) * LPS <= 63, "vmcnt holds 6 bits");
       if (NST == 2 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -511,6 +529,7 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
       else if (ahead == 5 || NST <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 6 ? 5 : 0) * LPS) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 7 ? 6 : 0) * LPS) : "memory");
       __builtin_amdgcn_s_barrier();
+      if (WK > 1 && it >= total) continue;         // wave-uniform: this group has run out of chunks
       if (ABL == 1) {
         if (issued < total) { issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
         rd = rd + 1 == NST ? 0 : rd + 1;
@@ -542,6 +561,37 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
       }
       rd = rd + 1 == NST ? 0 : rd + 1;
     }
+  }
+
+  if (WK > 1) {
+    // k-groups 1 .. WK-1 -> group 0, through LDS (the rings are idle: every issued chunk has been waited for and read).  Register r
+    // of lane l of wave w travels as one float at [(g-1)][w][tile][r][l]: lane-contiguous, conflict-free; group 0 adds the groups in
+    // ascending order, so the sum is bit-reproducible.
+    float* sRed = reinterpret_cast<float*>(smem_all);
+    constexpr int PER_WAVE = MI * NI * 16 * 64, PER_GRP = NW * PER_WAVE;
+    __syncthreads();
+    if (kgrp > 0) {
+      float* dst = sRed + (size_t)(kgrp - 1) * PER_GRP + wave * PER_WAVE + lane;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((mi * NI + ni) * 16 + r) * 64] = acc[mi][ni][r];
+    }
+    __syncthreads();
+    if (kgrp > 0) return;              // whole waves exit: s_barrier counts the surviving waves only
+#pragma unroll
+    for (int g = 1; g < WK; ++g) {
+      const float* src = sRed + (size_t)(g - 1) * PER_GRP + wave * PER_WAVE + lane;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * NI + ni) * 16 + r) * 64];
+    }
+    smem_raw = smem_all;               // the epilogue stages from the start of LDS
   }
 
   if (p.epi_lds && p.splitk <= 1) {
@@ -732,9 +782,9 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   }
 }
 
-template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0>
+template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
 static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t* zero_page) {
-  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM>;
+  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>;
   GemmP p = p_in;
   p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
   {
@@ -747,9 +797,9 @@ static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t
   constexpr int lds = GEO::LDS;
   static unsigned long long attr_devs = 0;
   if (first_on_device(attr_devs)) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL><<<grid, GEO::NT, lds, st>>>(p, zero_page);
+  igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL, WK><<<grid, GEO::NT_ALL, lds, st>>>(p, zero_page);
   return 0;
 }
 
@@ -886,16 +936,18 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (force_split > 1) {
     split = force_split;
   }
+  if (cfg >= 8 && !dma_ok) cfg = (cfg == 8 || cfg == 11) ? 1 : 0;
   if (cfg >= 3 && !dma_ok) cfg = 0;                                 // 256x128 / 128x320 / 128x256 exist only as LDS-DMA kernels
   // whatever chose the split (cost model or a caller-forced value): the slabs must fit the workspace and each split needs work
   if (split > 1) {
     if (split > nchunks) split = nchunks;
     if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu || cfg == 3) split = 1;
   }
-  if (cfg_used) *cfg_used = split > 1 ? 2 : (cfg >= 4 ? 9 : (cfg == 1 ? 1 : 0));
+  const bool c64 = cfg == 1 || cfg == 8 || cfg == 11, c256m = cfg == 3 || cfg == 6 || cfg == 7;
+  if (cfg_used) *cfg_used = split > 1 ? 2 : ((cfg >= 4 && cfg <= 7) ? 9 : (c64 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
-  const int bn_sel = (cfg == 4 || cfg == 6) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (cfg == 1 ? 64 : 128));
+  const int bn_sel = (cfg == 4 || cfg == 6) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (c64 ? 64 : 128));
   const bool vt_none = p.vt_col0 >= p.N;
   // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay
   // inside one batch item
@@ -906,8 +958,8 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.res_late = g_res_late;
   if (p.geglu && !(p.epi_lds && dma_ok && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
-  const int bm = (cfg == 3 || cfg >= 6) ? 256 : (cfg == 1 ? 64 : 128);
-  const int bn = (cfg == 4 || cfg == 6) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (cfg == 1 ? 64 : 128));
+  const int bm = c256m ? 256 : (c64 ? 64 : 128);
+  const int bn = bn_sel;
   if (stats_tile_rows) *stats_tile_rows = p.stats ? bm : 0;
   p.slab = ws;
   dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, split);
@@ -936,6 +988,14 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
       case 12: r = launch_dma<128, 320, 32, 2, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
       default: r = launch_dma<128, 320, 32, 2>(p, grid, st, g_zero_page); break;      // 56 KB ring, two-pass epilogue, 2 blocks / CU
     }
+  } else if (cfg == 8) {
+    r = launch_dma<64, 64, 64, 2, 2, 0, 4>(p, grid, st, g_zero_page);      // 16 waves: 4 k-groups
+  } else if (cfg == 11) {
+    r = launch_dma<64, 64, 64, 2, 2, 0, 2>(p, grid, st, g_zero_page);      // 8 waves: 2 k-groups, 64 KB (2 blocks / CU)
+  } else if (cfg == 9) {
+    r = launch_dma<128, 128, 32, 3, 2, 0, 2>(p, grid, st, g_zero_page);    // 8 waves: 2 k-groups, 96 KB
+  } else if (cfg == 10) {
+    r = launch_dma<128, 128, 64, 2, 2, 0, 2>(p, grid, st, g_zero_page);    // 8 waves: 2 k-groups, 128-byte rows, 128 KB
   } else if (cfg == 6) {
     r = launch_dma<256, 320, 64, 2, 4>(p, grid, st, g_zero_page);
   } else if (cfg == 7) {

@@ -73,3 +73,40 @@ def test_word_tokenizer_truncation_keeps_eos():
     assert len(ids) == 77 and ids[0] == BOS and ids[-1] == EOS and EOS not in ids[1:-1]
     rows = tok([" ".join("w%d" % i for i in range(100)), "a b"], padding="max_length", max_length=77).input_ids
     assert rows.shape == (2, 77) and int(rows[0, -1]) == EOS and int(rows[1, 3]) == EOS
+
+
+def test_pixel_metrics_against_independent_implementations():
+    """pnpinversion_amd.metrics (PSNR / MSE / SSIM of evaluation/matrics_calculator.py:304-383, torchmetrics' definitions) against an
+    independent evaluation: scipy.ndimage gaussian correlation with mirror boundaries for SSIM's windowed moments."""
+    import scipy.ndimage as ndi
+    from pnpinversion_amd import metrics
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, size=(96, 80, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-20, 21, size=a.shape), 0, 255).astype(np.uint8)
+    fa, fb = a.astype(np.float64) / 255, b.astype(np.float64) / 255
+    mse = np.mean((fa - fb) ** 2)
+    assert abs(metrics.calculate_mse(a, b) - mse) < 1e-9
+    assert abs(metrics.calculate_psnr(a, b) - 10 * np.log10(1 / mse)) < 1e-6
+    assert metrics.calculate_psnr(a, a) == float("inf") and metrics.calculate_ssim(a, a) == 1.0
+    # SSIM: full-image gaussian moments with mirror ("reflect" in torch's naming) boundaries == pad-by-5 + valid window + crop-by-5
+    # only in the interior; compare on the interior [10:-10] where both formulations see real pixels only
+    x = np.arange(11) - 5.0
+    g = np.exp(-(x / 1.5) ** 2 / 2); g /= g.sum()
+    def blur(z):
+        return ndi.correlate1d(ndi.correlate1d(z, g, axis=0, mode="mirror"), g, axis=1, mode="mirror")
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    maps = []
+    for ch in range(3):
+        p, t = fa[:, :, ch], fb[:, :, ch]
+        mp, mt = blur(p), blur(t)
+        spp, stt, spt = blur(p * p) - mp * mp, blur(t * t) - mt * mt, blur(p * t) - mp * mt
+        maps.append(((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp * mp + mt * mt + c1) * (spp + stt + c2)))
+    full = np.stack(maps, -1)
+    # torchmetrics' map is the centre crop [5:-5, 5:-5] of the map computed on the reflect-padded image, i.e. the [5:-5] crop of `full`
+    want = full[5:-5, 5:-5].mean()
+    assert abs(metrics.calculate_ssim(a, b) - want) < 1e-9, (metrics.calculate_ssim(a, b), want)
+    m = np.zeros((96, 80, 3), np.float32); m[20:60, 10:50] = 1
+    assert metrics.calculate_mse(a, b, 1 - m, 1 - m) < metrics.calculate_mse(a, b)
+    panel = np.concatenate([a[:80], a[:80], b[:80], b[:80]], axis=1)
+    rep = metrics.panel_report(panel, mask=m[:80, :, 0])
+    assert set(rep) >= {"recon_psnr", "edit_ssim", "psnr_unedit_part"} and abs(rep["recon_mse"] - metrics.calculate_mse(b[:80], a[:80])) < 1e-12
