@@ -229,6 +229,14 @@ int pnpi_direct_edit(pnpi_ctx* ctx, const float* ddim_latents /*[nsteps+1][nimg]
                      float guidance_scale, const float* offset_scale_host /*[nsteps], nullable*/, float* noise_loss_out,
                      float* latents_out);
 
+/* The pruned-equivalent schedule (SURVEY.md 8a Note D; an algebraic reformulation of the same edit, parity-tested against the
+ * faithful loops): with the direct-inversion offset the source latent of every step IS x*_{t-1}, so it is assigned from the stored
+ * inversion trajectory and only [uncond_tgt, cond_src, cond_tgt] are evaluated -- one 3-row UNet launch per step and image, 200
+ * sample-forwards per image instead of 650.  latents_out [nimg][2][4][h][w] = (x*_0, edited latent). */
+int pnpi_direct_edit_pruned(pnpi_ctx* ctx, const float* ddim_latents, int nimg, const float* context4,
+                            const pnpi_ctrl_desc* ctrl_host /* nullable or [nimg] */, int nsteps, const int* timesteps_host,
+                            float guidance_scale, float* latents_out);
+
 /* ---- kernel-level entry points (used by tests/ and bench.py to exercise single kernels) ------------------------- */
 int pnpi_op_conv(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nhwc_f16, int C1, int C2, int B, int H, int W,
                  int ksize, int stride, int pad, int upsample, int Ho, int Wo, const void* w_f16 /*[N][k*k*(C1+C2)]*/,

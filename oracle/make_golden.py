@@ -340,7 +340,7 @@ def proximal_recon(steps=4):
     from PIL import Image
     img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
     import models.p2p_editor as pe
-    out = {"steps": np.int64(steps), "src": src, "tgt": tgt, "blend": np.array([w0, w1]), "recon_lr": np.float32(0.5), "recon_t": np.int64(400),
+    out = {"steps": np.int64(steps), "src": src, "tgt": tgt, "blend": np.array([w0, w1]), "recon_lr": np.float32(0.1), "recon_t": np.int64(400),
            "dilate_mask": np.int64(1)}
     import models.p2p.inversion as inv
     for prox in ("l0", "l1"):
@@ -367,7 +367,7 @@ def proximal_recon(steps=4):
                 panel = ed("negative-prompt-inversion+proximal-guidance", image_path=img, prompt_src=src, prompt_tar=tgt,
                            guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
                            eq_params={"words": (w1,), "values": (2,)}, proximal=prox, quantile=0.75, use_reconstruction_guidance=True,
-                           recon_lr=0.5, recon_t=400, dilate_mask=1)
+                           recon_lr=0.1, recon_t=400, dilate_mask=1)
         finally:
             pe.proximal_guidance_forward = saved
             inv.NegativePromptInversion.invert = saved_inv

@@ -89,6 +89,7 @@ SYMBOLS = {
     "pnpi_offset_calculate": (_i, [_vp, _vp, _i, _vp, _i, _ip, _f, _fp, _vp]),
     "pnpi_edit_loop": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(CtrlDesc), _i, _ip, _f, _i, _f, C.POINTER(ReconDesc), _vp]),
     "pnpi_direct_edit": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CtrlDesc), _i, _i, _ip, _f, _fp, _vp, _vp]),
+    "pnpi_direct_edit_pruned": (_i, [_vp, _vp, _i, _vp, C.POINTER(CtrlDesc), _i, _ip, _f, _vp]),
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     "pnpi_op_conv_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _ip]),
     "pnpi_set_tuning": (_i, [C.c_char_p, _i]),

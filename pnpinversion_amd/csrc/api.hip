@@ -814,7 +814,7 @@ static int upload(pnpi_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 
 // Build the device-side tables for `rows` UNet rows (rows_per_image = 4 when controllers are active).
-static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows) {
+static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows, int rpi = 4, int src_off = 2, int tgt_off = 3) {
   CtrlDev& cd = c->cd;
   c->ctrl_arena.reset();
   cd = CtrlDev();
@@ -826,13 +826,14 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
   if (T > 96) return fail(c, PNPI_ESHAPE, "ctx_len > 96 unsupported by the cross-attention edit kernel");
   std::vector<int> edit_img;
   if (cds) {
-    if (rows != nimg * 4) return fail(c, PNPI_EINVAL, "controllers need rows == 4 * nimg");
+    if (rows != nimg * rpi) return fail(c, PNPI_EINVAL, "controllers need rows == rows_per_image * nimg");
     for (int i = 0; i < nimg; ++i) if (cds[i].kind == 1) edit_img.push_back(i);
   }
   if (cds) {   // MasaCtrl images (kind 2): rows [unc_src, unc_tgt, cond_src, cond_tgt]; each target row reads its half's source K, V
     std::vector<int> masa = id;
     for (int i = 0; i < nimg; ++i) {
       if (cds[i].kind != 2) continue;
+      if (rpi != 4) return fail(c, PNPI_EINVAL, "MasaCtrl controllers need the 4-row layout");
       if (cd.masa_any && (cd.masa_start_step != cds[i].masa_start_step || cd.masa_start_layer != cds[i].masa_start_layer))
         return fail(c, PNPI_EINVAL, "all MasaCtrl controllers of one batch must share start_step / start_layer");
       cd.masa_any = true; cd.masa_start_step = cds[i].masa_start_step; cd.masa_start_layer = cds[i].masa_start_layer;
@@ -850,7 +851,7 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
   cd.npairs = (int)edit_img.size();
   std::vector<bool> is_pair_row(rows, false);
   for (int i : edit_img) {
-    int src = i * 4 + 2, tgt = i * 4 + 3;
+    int src = i * rpi + src_off, tgt = i * rpi + tgt_off;
     rep[tgt * 4 + 1] = src; rep[tgt * 4 + 2] = src;  // q and k of the target row come from the source row
     pairs.push_back(src); pairs.push_back(tgt);
     is_pair_row[tgt] = true;   // only the target row leaves the plain path; the source row stays bit-identical to it
@@ -1617,6 +1618,64 @@ int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* c
     CKP(apply_local_blend(c, lat, i));
   }
   CKH(hipMemcpyAsync(latents_out, lat + (size_t)nimg * 2 * E, (size_t)npass * nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  return 0;
+}
+
+/* The pruned-equivalent schedule of SURVEY.md Note D (algebra, not approximation): in direct-inversion mode the source latent after
+ * every step is prev + (x*_{t-1} - prev) == x*_{t-1}, and no controller ever touches the unconditional rows or the conditional
+ * source row's output.  So the offset pass and the reconstruction pass are redundant, the source latent can be ASSIGNED from the
+ * stored trajectory, and the unconditional-source row is dead: one 3-row launch per step and image
+ * [uncond_tgt, cond_src (attention maps only), cond_tgt] instead of 12.  200 sample-forwards per image instead of 650.
+ * context4 rows as everywhere: [unc_src, unc_tgt, cond_src, cond_tgt] per image (row 0 is not used). */
+int pnpi_direct_edit_pruned(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host,
+                            int nsteps, const int* ts, float gs, float* latents_out) {
+  if (!c || !lat_all || !context4 || !ts || !latents_out || nsteps <= 0 || nimg <= 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  const int ratio = g.n_train_timesteps / nsteps, rows = 3 * nimg;
+  if (rows > c->max_rows) return fail(c, PNPI_EINVAL, "3 * nimg exceeds max_unet_rows");
+  std::vector<pnpi_ctrl_desc> none(nimg);
+  memset(none.data(), 0, none.size() * sizeof(pnpi_ctrl_desc));
+  CKP(setup_ctrl(c, ctrl_host ? ctrl_host : none.data(), nimg, rows, 3, 1, 2));
+  float* lat = misc_f(c, (size_t)nimg * 2 * E);      // [img][src, tgt]
+  float* in = misc_f(c, (size_t)rows * E);
+  float* eps = misc_f(c, (size_t)rows * E);
+  float* eps2 = misc_f(c, (size_t)nimg * 2 * E);     // [img][unc_tgt, cond_tgt]
+  float* xt = misc_f(c, (size_t)nimg * E);
+  float* ctx3 = misc_f(c, (size_t)rows * CE);
+  std::vector<int> expand(nimg * 2), inmap(rows), ctxmap(rows), epsmap(nimg * 2), tgtmap(nimg);
+  for (int i = 0; i < nimg; ++i) {
+    expand[2 * i] = i; expand[2 * i + 1] = i;
+    inmap[3 * i] = 2 * i + 1; inmap[3 * i + 1] = 2 * i; inmap[3 * i + 2] = 2 * i + 1;
+    ctxmap[3 * i] = 4 * i + 1; ctxmap[3 * i + 1] = 4 * i + 2; ctxmap[3 * i + 2] = 4 * i + 3;
+    epsmap[2 * i] = 3 * i; epsmap[2 * i + 1] = 3 * i + 2;
+    tgtmap[i] = 2 * i + 1;
+  }
+  int *d_expand, *d_inmap, *d_ctxmap, *d_epsmap, *d_tgtmap;
+  CKP(upload_ints(c, expand, &d_expand)); CKP(upload_ints(c, inmap, &d_inmap)); CKP(upload_ints(c, ctxmap, &d_ctxmap));
+  CKP(upload_ints(c, epsmap, &d_epsmap)); CKP(upload_ints(c, tgtmap, &d_tgtmap));
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  CK(launch_gather_rows_f32(lat_all + (size_t)nsteps * nimg * E, d_expand, nimg * 2, E, lat, c->st));      // both rows start from x*_T
+  CK(launch_gather_rows_f32(context4, d_ctxmap, rows, CE, ctx3, c->st));
+  LoopKV kv(c);
+  CKP(kv.begin(ctx3, rows));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[i];
+    CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
+    int r = unet_fwd(c, in, rows, t, ctx3, true, i, eps);
+    if (r) return r;
+    float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+    CK(launch_gather_rows_f32(eps, d_epsmap, nimg * 2, E, eps2, c->st));
+    CK(launch_gather_rows_f32(lat, d_tgtmap, nimg, E, xt, c->st));
+    CK(launch_cfg_ddim_prev(eps2, xt, nimg, 1, E, gs, af, at, nullptr, 0, nullptr, 1.f, nullptr, xt, c->st));
+    // source latent := x*_{t-1} (assigned, not reconstructed); target latent := the step's result
+    const float* target = lat_all + (size_t)(nsteps - i - 1) * nimg * E;
+    CKH(hipMemcpy2DAsync(lat, 2 * E * sizeof(float), target, E * sizeof(float), E * sizeof(float), nimg, hipMemcpyDeviceToDevice, c->st));
+    CKH(hipMemcpy2DAsync(lat + E, 2 * E * sizeof(float), xt, E * sizeof(float), E * sizeof(float), nimg, hipMemcpyDeviceToDevice, c->st));
+    CKP(apply_local_blend(c, lat, i));
+  }
+  CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
   return 0;
 }
 

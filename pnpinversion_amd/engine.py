@@ -339,6 +339,18 @@ class NativeEngine:
         self._keep = (lat, ctx, ts, arr, flat, sc)
         return nl, out
 
+    def direct_edit_pruned(self, ddim_latents, context4, ctrls, timesteps, guidance_scale):
+        """The pruned-equivalent schedule (SURVEY Note D): 3 rows per image and step, source latent assigned from the trajectory.
+        ctrls: None | list[ControllerTables | None] per image.  -> latents [nimg, 2, 4, h, w] = (x*_0, edited)"""
+        lat, ctx = self._f32(ddim_latents), self._f32(context4)
+        n, nimg = len(timesteps), lat.shape[1]
+        arr = _desc_array(ctrls)
+        out = torch.empty(nimg, 2, *lat.shape[2:], device=self.device)
+        ts, tsp = self._ts(timesteps)
+        self._call("pnpi_direct_edit_pruned", _p(lat), nimg, _p(ctx), arr, n, tsp, float(guidance_scale), _p(out))
+        self._keep = (lat, ctx, ts, arr, ctrls)
+        return out
+
     def edit_loop(self, x_T, context4, noise_loss, ctrls, timesteps, guidance_scale, offset_rows=1, prox=None, quantile=0.7,
                   recon=None):
         """recon: None | dict(ref_image=[nimg,4,h,w] encoded source latent, recon_lr, recon_t, dilate_mask): reconstruction guidance

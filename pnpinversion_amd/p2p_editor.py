@@ -53,6 +53,11 @@ class P2PEditor:
         # lock-step schedule (pnpi_direct_edit): offsets + reconstruction pass + edit pass share one UNet launch per timestep.
         # False runs the reference's phase order call by call (invert -> forward -> forward); same results within tolerance.
         self.lockstep = True
+        # "faithful" (default): every UNet call of the reference is executed (650 sample-forwards per directinversion+p2p image).
+        # "pruned": the algebraically equivalent schedule of SURVEY.md Note D for "directinversion+p2p" -- the source latent of the
+        # edit pass is assigned from the stored inversion trajectory (it equals prev + offset exactly), which makes the offset pass,
+        # the reconstruction pass and the unconditional-source row redundant: 200 sample-forwards.  Opt-in; same panels.
+        self.schedule = "faithful"
         self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
 
     def __call__(self, edit_method, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None, quantile=0.7,
@@ -110,7 +115,9 @@ class P2PEditor:
             image_gt = np.array(Image.fromarray(image_gt).resize((side, side)))
         prompts = [prompt_src, prompt_tar]
         null_inversion = DirectInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
-        if self.lockstep and self.ldm_stable.engine.max_unet_rows >= 12:
+        if self.schedule not in ("faithful", "pruned"):
+            raise ValueError("P2PEditor.schedule must be 'faithful' or 'pruned'")
+        if (self.lockstep and self.ldm_stable.engine.max_unet_rows >= 12) or self.schedule == "pruned":
             return self._edit_lockstep(null_inversion, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                                        self_replace_steps, blend_word, eq_params, is_replace_controller, add_target, return_stages, side,
                                        inverse_guidance_scale, offset_scale)
@@ -248,14 +255,25 @@ class P2PEditor:
                                      blend_words=blend_word, equilizer_params=eq_params, num_ddim_steps=self.num_ddim_steps,
                                      device=self.device)
         register_attention_control(model, controller)
-        nl, lats = model.engine.direct_edit(torch.stack(x_stars), inv.context[None], [None, [controller.tables()]],
-                                            model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1,
-                                            offset_scale=offset_scale)
-        controller.cur_step += self.num_ddim_steps
-        # host-side panel work while the device is still in the loop (the calls above only enqueue)
-        image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
-        noise_loss_list = [nl[i, 0] for i in range(nl.shape[0])]
-        reconstruct_latent, latents = lats[0, 0], lats[1, 0]
+        if self.schedule == "pruned":
+            if add_target or offset_scale is not None:
+                raise NotImplementedError("the pruned schedule is the plain directinversion+p2p edit (full offset on the source row only)")
+            out = model.engine.direct_edit_pruned(torch.stack(x_stars), inv.context[None], [controller.tables()],
+                                                  model.scheduler.timesteps.numpy(), guidance_scale)
+            controller.cur_step += self.num_ddim_steps
+            image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
+            noise_loss_list = None                                     # never materialised: latents[0] := x*_{t-1}
+            latents = out[0]
+            reconstruct_latent = torch.stack([out[0, 0], out[0, 0]])   # the reconstruction pass only reproduces x*_0 (Note D i)
+        else:
+            nl, lats = model.engine.direct_edit(torch.stack(x_stars), inv.context[None], [None, [controller.tables()]],
+                                                model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1,
+                                                offset_scale=offset_scale)
+            controller.cur_step += self.num_ddim_steps
+            # host-side panel work while the device is still in the loop (the calls above only enqueue)
+            image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
+            noise_loss_list = [nl[i, 0] for i in range(nl.shape[0])]
+            reconstruct_latent, latents = lats[0, 0], lats[1, 0]
         reconstruct_image = latent2image(model=model.vae, latents=reconstruct_latent)[0]
         images = latent2image(model=model.vae, latents=latents)
         panel = Image.fromarray(np.concatenate((image_instruct, image_gt, reconstruct_image, images[-1]), axis=1))

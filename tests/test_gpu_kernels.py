@@ -510,9 +510,10 @@ def test_reconstruction_guidance_step_bit_exact(ctx, prox, dil):
     from oracle import p2p_oracle as po
     from pnpinversion_amd import _capi
     g = torch.Generator().manual_seed(12)
-    eps = torch.randn(4, 4, 64, 64, generator=g)
-    x = torch.randn(2, 4, 64, 64, generator=g)
-    ref = torch.randn(1, 4, 64, 64, generator=g)
+    S = ctx.cfg.sample_size                                     # the library takes the plane size from its model configuration
+    eps = torch.randn(4, 4, S, S, generator=g)
+    x = torch.randn(2, 4, S, S, generator=g)
+    ref = torch.randn(1, 4, S, S, generator=g)
     ac, ratio, lr = po.alphas_cumprod(), 20, 0.1
     ctx.call("pnpi_set_scheduler", (C.c_float * 1000)(*ac.tolist()), 1000, float(ac[0]))
     ed, xd, rd = eps.cuda(), x.cuda(), ref.cuda()
