@@ -32,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 UNET_GFLOP = 803.27          # per sample-forward
+TEXT_KV_GFLOP = 2.95         # of which: the 32 cross-attention to_k / to_v projections of the text context -- executed once
+                             # per loop and context row by the text K/V cache instead of inside every forward
 VAE_ENC_TFLOP, VAE_DEC_TFLOP = 1.117, 2.515
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16, MI355X_MICROARCH.md
 PROMPT_SRC = "a cat sitting on a wooden chair"
@@ -69,13 +71,14 @@ def cpu_baseline(cfg, budget_s=40.0):
         else:
             t["unet_b4"] = 4 * t["unet_b1"]
             b4_note = "UNet B=4 taken as 4x B=1"
-        # VAE at 256x256 (1/4 of the pixels), scaled x4: conv cost is linear in pixels
-        img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
-        t0 = time.perf_counter(); sd_oracle.vae_encode_mean(vsd, cfg, img); t["vae_enc"] = 4 * (time.perf_counter() - t0)
-        t0 = time.perf_counter(); sd_oracle.vae_decode(vsd, cfg, lat[:1, :, :32, :32].contiguous()); t["vae_dec"] = 4 * (time.perf_counter() - t0)
+        # VAE at the full 512 x 512 (its attention block is quadratic in pixels: no scaling from a smaller size)
+        S = cfg.sample_size * cfg.vae_scale
+        img = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+        t0 = time.perf_counter(); sd_oracle.vae_encode_mean(vsd, cfg, img); t["vae_enc"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); sd_oracle.vae_decode(vsd, cfg, lat[:1]); t["vae_dec"] = time.perf_counter() - t0
     per_image = 50 * t["unet_b1"] + 150 * t["unet_b4"] + t["vae_enc"] + 5 * t["vae_dec"]
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "oracle fp32, %d threads: 1x UNet B=1 (%.2fs), %s, VAE enc+dec at 256^2 x4 (%.2fs, %.2fs); scaled x(50, 150, 1, 5) "
+            "sample": "oracle (CPU port of the reference's fp32 path; the reference itself is not on this box) fp32, %d threads: 1x UNet B=1 (%.2fs), %s, VAE enc + dec at 512^2 (%.2fs, %.2fs); scaled x(50, 150, 1, 5) "
                       "= %.0f s/image; sample wall %.0fs" % (threads, t["unet_b1"], b4_note, t["vae_enc"], t["vae_dec"], per_image,
                                                              time.perf_counter() - start)}
 
@@ -102,7 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="process-launch / rendezvous plumbing only, on CPU with gloo (tests)")
     ap.add_argument("--ddim-steps", type=int, default=50)
-    ap.add_argument("--batch-images", type=int, default=4,
+    ap.add_argument("--batch-images", type=int, default=8,
                     help="after the headline measurement (one image at a time), also time this many images per set of launches "
                          "(configs[2] style sweep batching; reported under \"batched\", never as value); 0/1 = skip")
     ap.add_argument("--schedule", choices=("lockstep", "reference"), default="lockstep",
@@ -195,13 +198,19 @@ def main():
     ctr = eng.counters()
     assert panel.size == (2048, 512)
 
+    def executed_flops(c):
+        """algorithmic FLOPs actually executed: forwards that read the text K/V cache do not project the context"""
+        fw, cached = c["unet_sample_forwards"], c["unet_sample_forwards_cached_kv"]
+        return ((fw - cached) * UNET_GFLOP + cached * (UNET_GFLOP - TEXT_KV_GFLOP) + c["text_kv_rows"] * TEXT_KV_GFLOP) * 1e9 + \
+            c["vae_encodes"] * VAE_ENC_TFLOP * 1e12 + c["vae_decodes"] * VAE_DEC_TFLOP * 1e12
+
     # per-kernel-class roofline: one more full edit with every launch bracketed by HIP events (rank 0, outside the timed region)
     roofline, classes = None, None
     if rank == 0:
         eng.profile_begin()
         one_edit(999)
         classes = eng.profile_end()
-        gemm = {k: classes[k] for k in ("igemm128", "igemm64", "igemm64_splitk")}
+        gemm = {k: classes[k] for k in ("igemm128", "igemm64", "igemm64_splitk", "igemm_wide")}
         dom = max(gemm, key=lambda k: gemm[k]["total_ms"])
         tot_ms = sum(v["total_ms"] for v in gemm.values())
         tot_fl = sum(v["flops"] for v in gemm.values())
@@ -216,6 +225,27 @@ def main():
                                     "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["total_ms"] > 0 and v["flops"] > 0 else None,
                                     "GBps": (v["bytes"] / (v["total_ms"] * 1e-3) / 1e9) if v["total_ms"] > 0 and v["bytes"] > 0 else None}
                                 for k, v in classes.items()}}
+
+    # extra (never `value`): the pruned-equivalent schedule of SURVEY Note D, FLOPs from the library's counters
+    pruned = None
+    if args.schedule == "lockstep":
+        editor.schedule = "pruned"
+        one_edit(999)
+        barrier()
+        eng.reset_counters()
+        tp = time.perf_counter()
+        one_edit(999)
+        barrier()
+        dtp = time.perf_counter() - tp
+        cp = eng.counters()
+        editor.schedule = "faithful"
+        if dist is not None:
+            tt = torch.tensor([dtp], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtp = float(tt.item())
+        pruned = {"value": world / dtp, "unit": "images/s", "ms_per_image": dtp * 1e3, "unet_sample_forwards_per_image": cp["unet_sample_forwards"],
+                  "executed_tflop_per_image": executed_flops(cp) / 1e12, "executed_tflops_per_gpu": executed_flops(cp) / dtp / 1e12,
+                  "note": "same edit, source latent assigned from the inversion trajectory (3-row launches); parity-tested against the faithful schedule"}
 
     batched = None
     if args.batch_images > 1 and args.schedule == "lockstep":
@@ -253,8 +283,7 @@ def main():
                     roofline["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, mean per launch)"
                     break
         n_img = args.steps * world
-        per_rank_flops = (ctr["unet_sample_forwards"] * UNET_GFLOP * 1e9 + ctr["vae_encodes"] * VAE_ENC_TFLOP * 1e12 +
-                          ctr["vae_decodes"] * VAE_DEC_TFLOP * 1e12)
+        per_rank_flops = executed_flops(ctr)
         out = {
             "metric": "edited images/sec @ 512x512, 50 DDIM-inv + 50 denoise steps",
             "value": n_img / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -262,7 +291,7 @@ def main():
             "dtype": "f16 (fp32 accumulate; latents / scheduler math fp32)", "data": "synthetic",
             "config": {"workload": "single 512x512 image per rank, SD-1.x (seeded synthetic weights), directinversion+p2p, "
                                    "faithful schedule: 650 UNet sample-forwards + 1 VAE encode + 5 VAE decodes per image, "
-                                   "Refine+Reweight+LocalBlend controller",
+                                   "Refine+Reweight+LocalBlend controller; text K/V projected once per loop (not per forward)",
                        "ddim_steps": args.ddim_steps, "images_per_step_per_gpu": 1, "schedule": args.schedule,
                        "unet_sample_forwards_per_image": ctr["unet_sample_forwards"] / max(1, args.steps),
                        "algorithmic_tflop_per_image": per_rank_flops / max(1, args.steps) / 1e12},
@@ -270,6 +299,8 @@ def main():
             "whole_path_mfma_frac": per_rank_flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
             "roofline": roofline,
         }
+        if pruned is not None:
+            out["pruned_schedule"] = pruned
         if batched is not None:
             out["batched"] = batched
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, see cpu_baseline)

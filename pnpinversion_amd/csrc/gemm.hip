@@ -835,6 +835,7 @@ static half_t* g_zero_page = nullptr;
 static constexpr size_t ZERO_PAGE_BYTES = 128 << 10;   // >= 2 * (longest K + one chunk): out-of-range rows walk it like real rows
 static int g_wide = 1;      // PNPI_IGEMM_WIDE=0: never pick the 128x320 / 128x256 tiles (ablation)
 static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
+static int g_use_table = 1;    // tuning "igemm_table" = 0: cost model only (no measured per-shape table)
 static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in the store loop (fp16(fp16(acc + bias) + res)) instead of staged
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
@@ -845,7 +846,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -876,10 +877,17 @@ int igemm_init() {
 // with split-K forced), 3 = 256x128 (ablation), 4 = 128x320, 5 = 128x256.
 struct TileCfg { int id, bm, bn; double rate, t_fix; int bpc; };   // rate: FLOP/s of the whole chip with every CU full; t_fix: per-tile
 static const TileCfg kTiles[] = {                                  // prologue + epilogue seconds; bpc: co-resident blocks per CU
-  {0, 128, 128, 863e12, 1.20e-6, 3},
-  {1, 64, 64, 594e12, 0.29e-6, 4},
-  {4, 128, 320, 997e12, 4.85e-6, 2},
-  {5, 128, 256, 1080e12, 3.76e-6, 2},
+  {0, 128, 128, 868e12, 1.22e-6, 3},
+  {1, 64, 64, 572e12, 0.25e-6, 4},
+  {4, 128, 320, 1228e12, 5.15e-6, 2},
+  {5, 128, 256, 1178e12, 3.61e-6, 2},
+};
+// Measured choices for the SD-1.x layer shapes at the row counts of the benchmarked schedule (1-row inversion, 12-row lock step):
+// per-shape best of every tile / split-K / k-group configuration (tools/autotune2.py -> tools/gen_tile_table.py).  The cost model
+// below covers every other shape (other row counts, other model widths).
+struct TileEntry { int M, N, K, ks, cfg, split; };
+static const TileEntry kTileTable[] = {
+#include "tile_table.inc"
 };
 // experimental 8-wave tiles (cfg 6 = 256x320, cfg 7 = 256x256; 128-byte rows, two stages, one block per CU): force_cfg only
 
@@ -898,6 +906,16 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   int cfg = force_cfg;
   int split = 1;
   if (cfg < 0 && g_force_cfg >= 0) cfg = g_force_cfg == 2 ? 1 : g_force_cfg;
+  if (cfg < 0 && g_use_table && dma_ok) {
+    for (const TileEntry& e : kTileTable)
+      if (e.M == p.M && e.N == p.N && e.K == p.K && e.ks == p.ksize) {
+        const int ebn = (e.cfg == 4 || e.cfg == 6) ? 320 : ((e.cfg == 5 || e.cfg == 7) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
+        const bool split_ok = e.split == 1 || (!p.geglu && ws && (size_t)e.split * p.M * p.N * sizeof(float) <= ws_bytes);
+        const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
+        if (split_ok && vt_ok && (g_wide || e.cfg < 4)) { cfg = e.cfg; split = e.split; }
+        break;
+      }
+  }
   if (cfg < 0) {
     // Tile / split-K selection by a small cost model (constants fitted to per-shape timings on MI355X, tools/fit_cost_model.py):
     //   time ~ (units on the busiest CU) x (padded FLOPs of one unit) / (per-CU rate of the tile x co-residency factor)
@@ -920,9 +938,9 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
         const double per_cu = (double)units / 256.0;
         // co-resident blocks cover each other's exposed loads: a lone block on a CU runs below the tile's full rate
         const double fill = per_cu >= tc.bpc ? 1.0 : (per_cu <= 1.0 ? 0.0 : (per_cu - 1.0) / (tc.bpc - 1.0));
-        const double resid = 0.835 + 0.165 * fill;
+        const double resid = 0.82 + 0.18 * fill;
         double t = (double)on_busiest * unit / resid;
-        if (s > 1) t += (double)(2 * s + 1) * p.M * p.N * 4.0 / 8.77e12 + 4.94e-6;   // slabs written, re-read, output + the reduce launch
+        if (s > 1) t += (double)(2 * s + 1) * p.M * p.N * 4.0 / 8.14e12 + 4.97e-6;   // slabs written, re-read, output + the reduce launch
         if (p.vt_col0 < p.N && p.vt_col0 % tc.bn != 0) t *= 1.3;   // transposed columns not tile-aligned: scalar epilogue
         if (t < best) { best = t; cfg = tc.id; split = s; }
       }

@@ -6,7 +6,9 @@ import json, math, os, sys
 import numpy as np
 from scipy.optimize import least_squares
 
-TILES = {"128": (128, 128, 3), "64": (64, 64, 4), "320": (128, 320, 2), "256n": (128, 256, 2)}     # default variants (v1)
+TILES = {"128": (128, 128, 3), "64": (64, 64, 4), "320": (128, 320, 2), "256n": (128, 256, 2)}      # default variants (v1)
+if os.environ.get("FIT_ALL_TILES"):
+    TILES.update({"128k2b": (128, 128, 1), "64k2": (64, 64, 2), "256x256": (256, 256, 1), "256x320": (256, 320, 1)})
 names = list(TILES)
 rows = []
 for path in sys.argv[1:]:
@@ -27,7 +29,8 @@ def predict(p, M, N, K, base, s):
     i = names.index(base)
     bm, bn, bpc = TILES[base]
     rate, tfix = p[2 * i] * 1e12, p[2 * i + 1] * 1e-6
-    t_launch, r1, bw, t_red = p[8] * 1e-6, p[9], p[10] * 1e12, p[11] * 1e-6
+    NT = 2 * len(names)
+    t_launch, r1, bw, t_red = p[NT] * 1e-6, p[NT + 1], p[NT + 2] * 1e12, p[NT + 3] * 1e-6
     nch = (K + 63) // 64
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
     units = tiles * s
@@ -42,16 +45,17 @@ def predict(p, M, N, K, base, s):
 def resid_fn(p):
     return [math.log(predict(p, M, N, K, b, s) / us) for (M, N, K, b, s, us) in rows]
 
-p0 = [840, 1.0, 520, 0.5, 1050, 2.0, 1000, 1.5, 3.0, 0.7, 2.5, 8.0]
-lo = [300, 0, 200, 0, 300, 0, 300, 0, 0, 0.3, 0.5, 0]
-hi = [2500, 20, 2500, 20, 2500, 20, 2500, 20, 20, 1.0, 10, 50]
+p0 = [840, 1.0] * len(names) + [3.0, 0.7, 2.5, 8.0]
+lo = [200, 0] * len(names) + [0, 0.3, 0.5, 0]
+hi = [3000, 30] * len(names) + [20, 1.0, 12, 50]
 sol = least_squares(resid_fn, p0, bounds=(lo, hi))
 p = sol.x
 r = np.array(resid_fn(p))
 print("rms log error %.3f" % math.sqrt((r ** 2).mean()))
 for i, n in enumerate(names):
     print("  %-7s rate %.0f TF  t_fix %.2f us" % (n, p[2 * i], p[2 * i + 1]))
-print("  t_launch %.2f us  resid(1 block/CU) %.2f  slab bw %.2f TB/s  t_reduce %.2f us" % (p[8], p[9], p[10], p[11]))
+NT = 2 * len(names)
+print("  t_launch %.2f us  resid(1 block/CU) %.2f  slab bw %.2f TB/s  t_reduce %.2f us" % (p[NT], p[NT + 1], p[NT + 2], p[NT + 3]))
 # regret of the model's choice per shape
 tot_pick = tot_best = 0.0
 for path in sys.argv[1:]:
