@@ -156,6 +156,16 @@ int pnpi_profile_end(pnpi_ctx* ctx, pnpi_kernel_stats* out /* [PNPI_KC_COUNT] */
 /* model.unet(latents, t, encoder_hidden_states=context)["sample"]    inversion.py:273, p2p_guidance_forward.py:109 */
 int pnpi_unet_forward(pnpi_ctx* ctx, const float* latents, int rows, int rows_per_image, int t, const float* context,
                       const pnpi_ctrl_desc* ctrl_host /* nullable, [rows/4] */, int cur_step, float* eps_out);
+/* Level-1 fallback for attention controllers the library has no descriptor for: the hooked attention forward of
+ * models/p2p/attention_control.py:20-47 executed literally.  While a callback is set, every attention site of pnpi_unet_forward
+ * materialises attn = softmax(q k^T * scale) as fp32 [rows*heads][Nq][Nk] (rows outer, heads inner: the reference's
+ * reshape_heads_to_batch_dim order) in `attn_buf`, calls cb -- which may rewrite the tensor in place with device work on the
+ * library's stream, as `attn = controller(attn, is_cross, place_in_unet)` does -- and then forms out = attn v.  place: 0 down,
+ * 1 mid, 2 up; layer: attention site 0..31 in call order.  A non-zero return from cb aborts the forward (PNPI_ESTATE).  Slow by
+ * construction (score tensors in HBM, one GEMM pair per (row, head)); the fused descriptor path is the product path.
+ * cb = NULL restores the fused path.  attn_buf must hold, for the largest site, rows*heads*Nq*Nk floats + Nq*round_up(Nk, 8) halfs. */
+typedef int (*pnpi_attn_callback)(void* user, float* attn, int rows, int heads, int Nq, int Nk, int is_cross, int place, int layer);
+int pnpi_set_attention_callback(pnpi_ctx* ctx, pnpi_attn_callback cb, void* user, float* attn_buf, size_t attn_buf_bytes);
 /* Cross-attention keys / values of the 16 transformer blocks for `rows` context rows (device fp32 [rows][77][768]); they depend on
  * the text only (CrossAttention.to_k / to_v on encoder_hidden_states, my_diffusers/models/attention.py:230-234, evaluated by the
  * reference inside every one of its 650 UNet calls per image).  pnpi_unet_forward(..., context = NULL, ...) then reads the cache

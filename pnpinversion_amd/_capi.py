@@ -41,6 +41,9 @@ class ReconDesc(C.Structure):
     _fields_ = [("ref_image", C.c_void_p), ("recon_lr", C.c_float), ("recon_t", C.c_int), ("dilate_mask", C.c_int)]
 
 
+ATTN_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+
+
 class Counters(C.Structure):
     _fields_ = [("unet_sample_forwards", C.c_uint64), ("unet_calls", C.c_uint64), ("vae_encodes", C.c_uint64),
                 ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double),
@@ -74,6 +77,7 @@ SYMBOLS = {
     "pnpi_profile_end": (_i, [_vp, C.POINTER(KernelStats)]),
     "pnpi_unet_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(CtrlDesc), _i, _vp]),
     "pnpi_text_kv_precompute": (_i, [_vp, _vp, _i]),
+    "pnpi_set_attention_callback": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "pnpi_local_blend": (_i, [_vp, _vp, _i, _i]),
     "pnpi_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pnpi_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -67,3 +67,8 @@ TINY16 = ModelConfig(block_out_channels=(32, 64, 64, 64), cross_dim=64, sample_s
 # 64x64 latents (needed by LocalBlend's hard-coded 16x16 maps) with narrow channels
 SMALL64 = ModelConfig(block_out_channels=(32, 64, 128, 128), cross_dim=64, sample_size=64, layers_per_block=2,
                       vae_block_out_channels=(32, 32, 64, 64), vae_layers_per_block=2, clip_layers=2, clip_heads=2, clip_intermediate=256)
+# SMALL64 without attention at the 64 x 64 level: LocalBlend's five 16 x 16 cross-attention maps (down_cross[2:4] + up_cross[:3] of the
+# stored <= 32^2-token maps) index the same layers, but the CPU oracle no longer materialises 4096 x 4096 self-attention tensors --
+# used for the full 50 + 50-step schedule against the oracle (22 attention sites instead of 32)
+SMALL64_LB = ModelConfig(block_out_channels=(32, 64, 128, 128), block_has_attn=(0, 1, 1, 0), cross_dim=64, sample_size=64, layers_per_block=2,
+                         vae_block_out_channels=(32, 32, 64, 64), vae_layers_per_block=2, clip_layers=2, clip_heads=2, clip_intermediate=256)

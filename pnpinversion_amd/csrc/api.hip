@@ -426,6 +426,38 @@ static int resnet_fwd(pnpi_ctx* c, const ResnetW& r, const half_t* x1, int C1, c
   return 0;
 }
 
+// The hooked attention forward of models/p2p/attention_control.py:20-47, literally: sim = q k^T * scale -> softmax -> controller(attn,
+// is_cross, place) -> attn v, with the probabilities materialised in fp32 for a host callback (level-1 fallback for controllers
+// without a descriptor).  One GEMM pair per (row, head); rows are not redirected (the callback does the editing).
+static int attn_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* vt, int ldv,
+                             half_t* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, int is_cross, int place,
+                             int layer) {
+  const int ldp = round_up_i(Nk, 8);
+  const size_t need = align_up((size_t)B * heads * Nq * Nk * sizeof(float), 256);
+  // the fp16 copy of one (row, head) probability block (the MFMA operand of P V) lives behind the fp32 tensor in the caller's buffer
+  if (!c->attn_buf || need + (size_t)Nq * ldp * sizeof(half_t) > c->attn_buf_bytes)
+    return fail(c, PNPI_ENOMEM, "attention callback buffer too small for this site (rows*heads*Nq*Nk floats + Nq*Nk halfs)");
+  half_t* p16 = reinterpret_cast<half_t*>(reinterpret_cast<char*>(c->attn_buf) + need);
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < heads; ++h) {
+      float* S = c->attn_buf + ((size_t)b * heads + h) * Nq * Nk;
+      VtOut v; v.outT = S; v.col0 = 0; v.ld = Nk; v.f32 = 1; v.rpb = Nk;      // outT[q][key] = scale * sum_d K[key][d] Q[q][d]
+      CK(op_gemm(c, k + (size_t)b * Nk * ldk + k_off + h * Dp, ldk, Nk, Dp, q + (size_t)b * Nq * ldq + q_off + h * Dp, ldq, Nq, nullptr,
+                 nullptr, 0, nullptr, Nq, scale, &v));
+    }
+  CK(launch_softmax_rows_f32(c->attn_buf, (size_t)B * heads * Nq, Nk, c->st));
+  CKH(hipStreamSynchronize(c->st));                 // the callback is host code: it sees finished probabilities
+  if (c->attn_cb(c->attn_cb_user, c->attn_buf, B, heads, Nq, Nk, is_cross, place, layer)) return fail(c, PNPI_ESTATE, "attention callback failed");
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < heads; ++h) {
+      const float* S = c->attn_buf + ((size_t)b * heads + h) * Nq * Nk;
+      CK(launch_f32_rows_to_f16_padded(S, Nq, Nk, ldp, p16, c->st));
+      CK(op_gemm(c, p16, ldp, Nq, ldp, vt + ((size_t)b * heads + h) * Dp * (size_t)ldv, ldv, dh, nullptr, nullptr, 0,
+                 o + (size_t)b * Nq * ldo + h * dh, ldo));
+    }
+  return 0;
+}
+
 // SpatialTransformer + BasicTransformerBlock (my_diffusers/models/attention.py:140-200) with the hooked attention of
 // models/p2p/attention_control.py:20-47 and the controller semantics of :178-190, :269-282 fused into the kernels.
 static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, int B, int H, int W, const half_t* ctx16,
@@ -461,7 +493,10 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     const bool masa = use_ctrl && cd.masa_any && cur_step >= cd.masa_start_step && block_index >= cd.masa_start_layer;
     a.rows = rep ? cd.rows_rep : (masa ? cd.rows_masa : cd.rows_id); a.nrows = B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
-    if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, N, N, t.Dp, launch_attn_flash(a, c->st));
+    if (c->attn_cb && !c->dry) {
+      if (ldv != N) CKH(hipMemsetAsync(vt, 0, (size_t)B * hd * ldv * sizeof(half_t), c->st));   // (never: token counts are multiples of 8)
+      CKP(attn_materialized(c, qk, 2 * hd, 0, qk, 2 * hd, hd, vt, ldv, ao, C, t.heads, N, N, t.Dp, t.dh, scale, B, 0, t.place, 2 * block_index));
+    } else if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, N, N, t.Dp, launch_attn_flash(a, c->st));
   }
   half_t* hs1 = talloc(c, (size_t)M * C);
   CK(op_gemm(c, ao, C, M, C, t.o1.w, C, C, t.o1.b, hs, C, hs1, C));
@@ -478,6 +513,8 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   } else {
     k2 = talloc(c, (size_t)B * T * hd);
     vt2 = talloc(c, (size_t)B * hd * ldv2);
+    // call-back path: the P V product runs over the padded key count, so the pad columns of V^T must be zeros (not stale arena bytes)
+    if (c->attn_cb && !c->dry && ldv2 != T) CKH(hipMemsetAsync(vt2, 0, (size_t)B * hd * ldv2 * sizeof(half_t), c->st));
     VtOut v; v.outT = vt2; v.col0 = hd; v.ld = ldv2; v.f32 = 0; v.rpb = T;
     CK(op_gemm(c, ctx16, X, B * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v, 2.0 * B * T * 2.0 * C * X));
   }
@@ -487,8 +524,10 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     a.rows = edit ? cd.rows_plain : cd.rows_id; a.nrows = edit ? cd.n_plain : B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * 96 * t.Dp;
-    if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * a.nrows * t.heads * (double)N * T * t.dh, 0.0, N, T, t.Dp, launch_attn_flash(a, c->st));
-    if (edit && !c->dry) {
+    if (c->attn_cb && !c->dry) {
+      CKP(attn_materialized(c, q2, hd, 0, k2, hd, 0, vt2, ldv2, ao2, C, t.heads, N, T, t.Dp, t.dh, scale, B, 1, t.place, 2 * block_index + 1));
+    } else if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * a.nrows * t.heads * (double)N * T * t.dh, 0.0, N, T, t.Dp, launch_attn_flash(a, c->st));
+    if (edit && !c->dry && !c->attn_cb) {
       CrossEditP e; e.q = q2; e.ldq = hd; e.q_off = 0; e.k = k2; e.ldk = hd; e.k_off = 0; e.vt = vt2; e.ldv = ldv2;
       e.o = ao2; e.ldo = C; e.heads = t.heads; e.Nq = N; e.Nk = T; e.Dp = t.Dp; e.dh = t.dh; e.scale = scale;
       e.pairs = cd.pairs; e.npairs = cd.npairs; e.mmatT = cd.mmatT;
@@ -1217,6 +1256,12 @@ static int check_clip_ready(pnpi_ctx* c) {
   return 0;
 }
 
+int pnpi_set_attention_callback(pnpi_ctx* c, pnpi_attn_callback cb, void* user, float* attn_buf, size_t attn_buf_bytes) {
+  if (!c || (cb && (!attn_buf || !attn_buf_bytes))) return PNPI_EINVAL;
+  c->attn_cb = cb; c->attn_cb_user = user; c->attn_buf = cb ? attn_buf : nullptr; c->attn_buf_bytes = cb ? attn_buf_bytes : 0;
+  return 0;
+}
+
 int pnpi_text_kv_precompute(pnpi_ctx* c, const float* context, int rows) {
   if (!c || !context) return PNPI_EINVAL;
   CKP(check_ready(c));
@@ -1228,6 +1273,7 @@ int pnpi_unet_forward(pnpi_ctx* c, const float* latents, int rows, int rows_per_
   if (!c || !latents || !eps_out) return PNPI_EINVAL;
   CKP(check_ready(c));
   if (!context && c->tkv.rows != rows) return fail(c, PNPI_ESTATE, "context is NULL: call pnpi_text_kv_precompute for this row count first");
+  if (c->attn_cb && (!context || ctrl_host)) return fail(c, PNPI_EINVAL, "attention callback: pass the context, and no controller descriptor");
   struct UseKV { pnpi_ctx* c; ~UseKV() { c->tkv.use = false; } } guard{c};
   c->tkv.use = context == nullptr;
   bool use_ctrl = false;

@@ -179,6 +179,10 @@ struct pnpi_ctx {
   float* bias_tab = nullptr;          // [n_train][temb_total]: conv1 bias + time embedding per TIMESTEP, filled on first use -- it depends
   std::vector<char> bias_valid;       // on t and the weights only, so every later forward at that timestep launches no GEMV
   TextKV tkv;
+  // level-1 fallback for controllers without a descriptor: materialise-and-call-back (pnpi_set_attention_callback)
+  pnpi_attn_callback attn_cb = nullptr;
+  void* attn_cb_user = nullptr;
+  float* attn_buf = nullptr; size_t attn_buf_bytes = 0;   // caller-owned device buffer the probabilities are materialised in
   std::unordered_map<std::string, Slot> slots;
   UNetW unet;
   VaeW vae;

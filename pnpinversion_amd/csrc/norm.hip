@@ -520,6 +520,44 @@ int launch_softmax_rows(half_t* x, int M, int N, int ld, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// fp32 variant for the materialised-attention call-back path (attention_control.py:40-41: softmax over the key axis of the
+// [B*heads, N, M] score tensor the reference hands to its controller).  One wavefront per row, in place.
+__global__ void __launch_bounds__(256) softmax_rows_f32_kernel(float* __restrict__ x, size_t M, int N) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float* p = x + row * N;
+  float mx = -INFINITY;
+  for (int c = lane; c < N; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += __expf(p[c] - mx);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane; c < N; c += 64) p[c] = __expf(p[c] - mx) * inv;
+}
+int launch_softmax_rows_f32(float* x, size_t M, int N, hipStream_t st) {
+  softmax_rows_f32_kernel<<<(unsigned)((M + 3) / 4), 256, 0, st>>>(x, M, N);
+  return (int)hipGetLastError();
+}
+// in [M][N] fp32 -> out [M][ld] fp16, columns [N, ld) zero (the probabilities as the MFMA operand of the P V product)
+__global__ void f32_rows_to_f16_padded_kernel(const float* __restrict__ in, size_t M, int N, int ld, half_t* __restrict__ out) {
+  const size_t total = M * (size_t)ld;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = idx / ld;
+    const int n = (int)(idx - m * ld);
+    out[idx] = n < N ? (half_t)in[m * N + n] : (half_t)0.f;
+  }
+}
+int launch_f32_rows_to_f16_padded(const float* in, size_t M, int N, int ld, half_t* out, hipStream_t st) {
+  size_t total = M * (size_t)ld;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  f32_rows_to_f16_padded_kernel<<<blocks, 256, 0, st>>>(in, M, N, ld, out);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ GEMV
 // out[n] = bias[n] + sum_k act(x[k]) * W[n][k]; one wavefront per output, fp32 accumulate (time-embedding MLP).
 __global__ void __launch_bounds__(256) gemv_kernel(const float* __restrict__ x, int K, const half_t* __restrict__ W, int N,

@@ -54,6 +54,8 @@ int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamm
                      hipStream_t st);
 int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st);       // x [M][2I] -> out [M][I]
 int launch_softmax_rows(half_t* x, int M, int N, int ld, hipStream_t st);            // in place, fp32 internally
+int launch_softmax_rows_f32(float* x, size_t M, int N, hipStream_t st);                  // in place, [M][N] contiguous
+int launch_f32_rows_to_f16_padded(const float* in, size_t M, int N, int ld, half_t* out, hipStream_t st);
 int launch_gemv(const float* x, int K, const half_t* W, int N, const float* bias, const float* bias2, int silu_in,
                 float* out, hipStream_t st);
 // weight repack (PyTorch layouts -> fp16 KRSC / head-padded rows, fp32 vectors)

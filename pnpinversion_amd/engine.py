@@ -196,12 +196,69 @@ class NativeEngine:
         self._call("pnpi_text_kv_precompute", _p(ctx), ctx.shape[0])
         self._keep_ctx = ctx
 
+    # ---- level-1 fallback: materialise-and-call-back attention (controllers without a kernel descriptor)
+    def attention_sites(self):
+        """(tokens, keys) of the 32 attention sites in call order -- sizes the call-back buffer"""
+        cfg, S, sites = self.cfg, self.cfg.sample_size, []
+        def level(i):
+            n = (S >> i) ** 2
+            return [(n, n), (n, cfg.ctx_len)]
+        for i in range(cfg.n_blocks):
+            if cfg.block_has_attn[i]:
+                sites += level(i) * cfg.layers_per_block
+        sites += level(cfg.n_blocks - 1)
+        for i in reversed(range(cfg.n_blocks)):
+            if cfg.block_has_attn[i]:
+                sites += level(i) * (cfg.layers_per_block + 1)
+        return sites
+
+    def set_attention_callback(self, fn, rows=None):
+        """fn(attn, is_cross: bool, place: 'down'|'mid'|'up', layer: int) -> None | tensor: called at every attention site of unet()
+        with the softmax probabilities as a float32 CUDA tensor [rows*heads, Nq, Nk] (the reference's hooked forward,
+        models/p2p/attention_control.py:40-44); it may modify the tensor in place or return a replacement.  fn = None removes it."""
+        if fn is None:
+            self._call("pnpi_set_attention_callback", None, None, None, 0)
+            self._cb_keep = None
+            return
+        rows = rows or self.max_unet_rows
+        heads = self.cfg.heads
+        need = max(rows * heads * nq * nk * 4 + nq * ((nk + 7) // 8 * 8) * 2 + 512 for nq, nk in self.attention_sites())
+        buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        base = buf.data_ptr()
+        places = ("down", "mid", "up")
+        err = []
+
+        def trampoline(user, attn_ptr, B, H, Nq, Nk, is_cross, place, layer):
+            try:
+                n = B * H * Nq * Nk
+                off = attn_ptr - base
+                view = buf[off:off + 4 * n].view(torch.float32).view(B * H, Nq, Nk)
+                with torch.cuda.device(self.device):
+                    new = fn(view, bool(is_cross), places[place], layer)
+                    if new is not None and new is not view:
+                        view.copy_(new.reshape(view.shape))
+                    torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception as e:       # never let an exception cross the C boundary
+                err.append(e)
+                return 1
+
+        cb = _capi.ATTN_CALLBACK(trampoline)
+        self._call("pnpi_set_attention_callback", cb, None, C.c_void_p(base), need)
+        self._cb_keep = (cb, buf, err)
+
     def unet(self, latents, t, context, rows_per_image=1, ctrls=None, cur_step=0):
         lat, ctx = self._f32(latents), (self._f32(context) if context is not None else None)
         rows = lat.shape[0]
         out = torch.empty_like(lat)
         arr = _desc_array(ctrls)
-        self._call("pnpi_unet_forward", _p(lat), rows, rows_per_image, int(t), _p(ctx), arr, int(cur_step), _p(out))
+        try:
+            self._call("pnpi_unet_forward", _p(lat), rows, rows_per_image, int(t), _p(ctx), arr, int(cur_step), _p(out))
+        except _capi.PnpiError:
+            keep = getattr(self, "_cb_keep", None)
+            if keep and keep[2]:
+                raise keep[2].pop()          # the exception raised inside the attention callback
+            raise
         self._keep = (lat, ctx, arr, ctrls)
         return out
 

@@ -190,9 +190,17 @@ def controller_tables(controller):
     if controller is None:
         return None
     if not hasattr(controller, "tables"):
-        raise TypeError("controller %s has no native descriptor (.tables()); build it with pnpinversion_amd.p2p.attention_control "
-                        "(same class names / arguments as models/p2p/attention_control.py)" % type(controller).__name__)
+        raise TypeError("controller %s has no native descriptor (.tables()) and is not callable as controller(attn, is_cross, place); "
+                        "build it with pnpinversion_amd.p2p.attention_control (same class names / arguments as "
+                        "models/p2p/attention_control.py)" % type(controller).__name__)
     return controller.tables()
+
+
+def is_callback_controller(controller):
+    """A controller object of the reference's protocol (models/p2p/attention_control.py:151-190: `controller(attn, is_cross,
+    place_in_unet)` at every attention site) for which the library has no kernel descriptor: it runs through the
+    materialise-and-call-back path of pnpi_set_attention_callback (slow, exact semantics)."""
+    return controller is not None and not hasattr(controller, "tables") and callable(controller)
 
 
 def register_attention_control(model, controller):

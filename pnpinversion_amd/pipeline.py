@@ -69,12 +69,23 @@ class NativeUNet:
         t = int(timestep)
         ctrls, cur_step, rpi = None, 0, 1
         c = self.controller
-        from .p2p.attention_control import controller_tables
+        from .p2p.attention_control import controller_tables, is_callback_controller
+        if is_callback_controller(c):
+            # level-1 fallback: an object of the reference's controller protocol without a kernel descriptor is called back
+            # on the materialised probabilities at each of the 32 attention sites, exactly as the reference's hooked forward does
+            # (attention_control.py:40-44).  The controller advances its own cur_step / cur_att_layer, as in the reference.
+            if getattr(self, "_cb_for", None) is not c:
+                self.engine.set_attention_callback(lambda attn, is_cross, place, layer: c(attn, is_cross, place))
+                self._cb_for = c
+            return {"sample": self.engine.unet(sample, t, encoder_hidden_states)}
+        if getattr(self, "_cb_for", None) is not None:
+            self.engine.set_attention_callback(None)
+            self._cb_for = None
         tables = controller_tables(c)        # raises for a controller object the library has no descriptor for
         if tables is not None:
             if rows % 4 != 0:
                 raise ValueError("an attention controller is registered: the UNet batch must be [uncond_src, uncond_tgt, cond_src, "
-                                 "cond_tgt] per image (rows %% 4 == 0), got %d rows" % rows)
+                                 "cond_tgt] per image (rows % 4 == 0), got %d rows" % rows)
             ctrls, cur_step, rpi = [tables] * (rows // 4), c.cur_step, 4
         eps = self.engine.unet(sample, t, encoder_hidden_states, rows_per_image=rpi, ctrls=ctrls, cur_step=cur_step)
         if c is not None and hasattr(c, "cur_step"):

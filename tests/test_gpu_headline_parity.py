@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 from oracle import p2p_oracle as po  # noqa: E402   (checker only)
 from oracle import sd_oracle  # noqa: E402
 from pnpinversion_amd import weights  # noqa: E402
-from pnpinversion_amd.config import SD1, SMALL64, TINY16  # noqa: E402
+from pnpinversion_amd.config import SD1, SMALL64, SMALL64_LB, TINY16  # noqa: E402
 from pnpinversion_amd.p2p import attention_control as ac  # noqa: E402
 from pnpinversion_amd.p2p_editor import P2PEditor  # noqa: E402
 from pnpinversion_amd.pipeline import NativePipeline  # noqa: E402
@@ -122,7 +122,7 @@ def oracle_tables(c, steps):
     return t
 
 
-@pytest.mark.parametrize("name", ["tiny16_replace_reweight", "small64_refine_reweight_localblend"])
+@pytest.mark.parametrize("name", ["tiny16_replace_reweight", "small64lb_refine_reweight_localblend"])
 def test_full_50_step_schedule_against_oracle(name):
     steps = 50
     if name.startswith("tiny16"):
@@ -130,7 +130,9 @@ def test_full_50_step_schedule_against_oracle(name):
         prompts = ["a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate"]
         eq = {"words": ("square",), "values": (2,)}
     else:
-        cfg, wseed, is_replace, blend = SMALL64, 2, False, (("cat",), ("dog",))
+        # 64 x 64 latents (LocalBlend's 16 x 16 maps) with attention at the 32^2 / 16^2 / 8^2 levels only: the CPU oracle would spend
+        # ten minutes materialising 4096 x 4096 self-attention tensors otherwise (the 64^2 sites are covered at 2-6 steps elsewhere)
+        cfg, wseed, is_replace, blend = SMALL64_LB, 2, False, (("cat",), ("dog",))
         prompts = ["a cat sitting on a wooden chair", "a dog sitting on a wooden chair"]
         eq = {"words": ("dog",), "values": (2,)}
     usd, vsd = weights.unet_state_dict(cfg, wseed), weights.vae_state_dict(cfg, wseed)
@@ -161,8 +163,9 @@ def test_full_50_step_schedule_against_oracle(name):
     # ---- oracle: the reference's phase order, fp32
     ref_lat = po.ddim_loop(unet_fn, z0, ctx[2:3], po.make_timesteps(steps), ac_, ac_[0])
     ref_nl = po.offset_calculate(unet_fn, ref_lat, ctx, po.make_timesteps(steps), ac_, ac_[0], 7.5)
-    ref_rec = po.guidance_forward(unet_fn, ref_lat[-1], ctx, ref_nl, po.StoreController(32), po.make_timesteps(steps), ac_, ac_[0], 7.5)
-    ref_out = po.guidance_forward(unet_fn, ref_lat[-1], ctx, ref_nl, po.EditController(32, oracle_tables(c, steps)),
+    nsites = pipe.unet.num_att_layers
+    ref_rec = po.guidance_forward(unet_fn, ref_lat[-1], ctx, ref_nl, po.StoreController(nsites), po.make_timesteps(steps), ac_, ac_[0], 7.5)
+    ref_out = po.guidance_forward(unet_fn, ref_lat[-1], ctx, ref_nl, po.EditController(nsites, oracle_tables(c, steps)),
                                   po.make_timesteps(steps), ac_, ac_[0], 7.5)
     # ---- native: the product's schedule (B=1 inversion loop, then one 12-row lock-step launch per timestep), all on its OWN trajectory
     got_lat = eng.ddim_invert(z0, ctx[2:3], ts)
@@ -183,35 +186,40 @@ def test_full_50_step_schedule_against_oracle(name):
     scale = max(1.0, float(ref_out[1].pow(2).mean().sqrt()))            # LocalBlend flips are judged relative to the latent scale
     r_out, frac = masked_rel(out[1], ref_out[1], pix_tol=0.25 * scale)
     r_out_all = rel(out[1], ref_out[1])
-    # Conditioning of the edit branch itself: the SAME fp32 oracle loop with each UNet output perturbed by one fp16 rounding
-    # (relative 2^-11) -- far less than any fp16-storage pipeline incurs.  With these random weights, guidance 7.5 and the x2
-    # equalizer the target branch is not a contraction, and the oracle moves by this much from that perturbation alone.
-    gen = torch.Generator().manual_seed(77)
-
-    def unet_fn_rounded(lat, t, c_, hook):
-        e = unet_fn(lat, t, c_, hook)
-        return e * (1 + 2.0 ** -11 * torch.randn(e.shape, generator=gen))
-
-    pert = po.guidance_forward(unet_fn_rounded, ref_lat[-1], ctx, ref_nl, po.EditController(32, oracle_tables(c, steps)),
-                               po.make_timesteps(steps), ac_, ac_[0], 7.5)
-    cond = rel(pert[1], ref_out[1])
-    drift.update(final_source_vs_z0=r_src, final_reconstruction_rel_l2=r_rec, final_edit_rel_l2=r_out_all,
-                 final_edit_rel_l2_outside_localblend_flips=r_out, localblend_mask_flip_fraction=frac, edit_latent_rms=scale,
-                 oracle_edit_rel_l2_under_one_fp16_rounding_per_step=cond)
     # decoded images: native VAE on native latents vs oracle VAE on oracle latents
     with torch.no_grad():
-        ref_img = po.latent2image(lambda z: sd_oracle.vae_decode(vsd, cfg, z), torch.stack([ref_rec[0], ref_out[1], pert[1]]))
+        ref_img = po.latent2image(lambda z: sd_oracle.vae_decode(vsd, cfg, z), torch.stack([ref_rec[0], ref_out[1]]))
     got_img = eng.latent2image(torch.stack([rec[0], out[1]])).cpu().numpy()
     d = [float(np.abs(got_img[i].astype(np.int32) - ref_img[i].astype(np.int32)).mean()) for i in range(2)]
     ps = [float(psnr_u8(got_img[i], ref_img[i])) for i in range(2)]
-    ps_cond = float(psnr_u8(ref_img[2], ref_img[1]))
+    # Conditioning of the edit branch itself, measured only when the stated bar is missed: the SAME fp32 oracle loop with each UNet
+    # output perturbed by one fp16 rounding (relative 2^-11) -- far less than any fp16-storage pipeline incurs.  With random weights,
+    # guidance 7.5 and the x2 equalizer the target branch is not a contraction, and the oracle itself can move by more than 2e-2.
+    cond, ps_cond = None, None
+    if not (r_out < 2e-2 and ps[1] >= 35.0):
+        gen = torch.Generator().manual_seed(77)
+
+        def unet_fn_rounded(lat, t, c_, hook):
+            e = unet_fn(lat, t, c_, hook)
+            return e * (1 + 2.0 ** -11 * torch.randn(e.shape, generator=gen))
+
+        pert = po.guidance_forward(unet_fn_rounded, ref_lat[-1], ctx, ref_nl, po.EditController(nsites, oracle_tables(c, steps)),
+                                   po.make_timesteps(steps), ac_, ac_[0], 7.5)
+        cond = rel(pert[1], ref_out[1])
+        with torch.no_grad():
+            pert_img = po.latent2image(lambda z: sd_oracle.vae_decode(vsd, cfg, z), pert[1:2])
+        ps_cond = float(psnr_u8(pert_img[0], ref_img[1]))
+    drift.update(final_source_vs_z0=r_src, final_reconstruction_rel_l2=r_rec, final_edit_rel_l2=r_out_all,
+                 final_edit_rel_l2_outside_localblend_flips=r_out, localblend_mask_flip_fraction=frac, edit_latent_rms=scale,
+                 oracle_edit_rel_l2_under_one_fp16_rounding_per_step=cond)
     drift.update(image_mean_abs_diff=d, image_psnr_db=ps, oracle_edit_image_psnr_db_under_one_fp16_rounding_per_step=ps_cond)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(drift, open(os.path.join(ROOT, "gpurun_out", "drift_%s.json" % name), "w"), indent=1)
     print("50+50 steps %s: inversion %.2e (max step %.2e), offsets max %.2e, source %.2e, recon %.2e, edit %.2e (outside %.3f%% flips "
-          "%.2e; oracle under one fp16 rounding per step %.2e), images mean|d| %.2f / %.2f, PSNR %.1f / %.1f dB (oracle perturbed %.1f dB)"
+          "%.2e%s), images mean|d| %.2f / %.2f, PSNR %.1f / %.1f dB"
           % (name, r_inv, max(drift["inversion_rel_l2_by_step"]), max(drift["offset_abs_err_over_latent_rms_by_step"]), r_src, r_rec,
-             r_out_all, 100 * frac, r_out, cond, d[0], d[1], ps[0], ps[1], ps_cond))
+             r_out_all, 100 * frac, r_out, "" if cond is None else "; oracle under one fp16 rounding per step %.2e / %.1f dB" % (cond, ps_cond),
+             d[0], d[1], ps[0], ps[1]))
     # SURVEY 8(d), 50 + 50 steps: final latents rel-L2 <= 2e-2, decoded images PSNR >= 35 dB / mean |diff| <= 2/255 -- asserted as
     # stated on the source branch (what direct inversion promises: x*_0 back) and the reconstruction pass's target row.
     assert r_src < 2e-2, r_src
@@ -221,8 +229,8 @@ def test_full_50_step_schedule_against_oracle(name):
     # The controller-edited target row gets the same bar wherever the branch is conditioned well enough for it to be meaningful;
     # where the fp32 oracle itself moves by more than 2e-2 under one fp16 rounding per step, the HIP path must stay within THAT.
     assert frac <= 0.005, frac
-    assert r_out < max(2e-2, cond), (r_out, cond)
-    assert ps[1] >= min(35.0, ps_cond), (ps, ps_cond)
+    assert r_out < 2e-2 or r_out < cond, (r_out, cond)
+    assert ps[1] >= 35.0 or ps[1] >= ps_cond, (ps, ps_cond)
     eng.close()
 
 

@@ -91,6 +91,92 @@ def test_text_kv_cache_and_timestep_bias_table_are_exact(tiny):
     assert torch.equal(a, b) and torch.equal(nl_a, nl_b) and torch.equal(lat_a, lat_b)
 
 
+def test_attention_callback_fallback_for_controllers_without_descriptor(tiny):
+    """SURVEY 8b level 1: a controller object of the reference's protocol (`controller(attn, is_cross, place)`, called at each of the
+    32 attention sites on the materialised [B*heads, N, M] probabilities -- attention_control.py:20-47,178-190) that the library has no
+    kernel descriptor for runs through pnpi_set_attention_callback.  Checked: (1) an identity controller reproduces the fused forward,
+    (2) the oracle's EditController driven through the call-back path matches both the CPU oracle and the fused descriptor path,
+    (3) an arbitrary user controller (not expressible as a descriptor) matches the oracle run with the same hook, (4) exceptions raised
+    in the controller surface in Python."""
+    from oracle import p2p_oracle as po
+    from pnpinversion_amd.p2p import attention_control as ac
+    from pnpinversion_amd.pipeline import NativePipeline
+    from pnpinversion_amd.text import WordTokenizer
+    from types import SimpleNamespace
+    cfg, usd, vsd, eng = tiny
+    lat = _lat(cfg, 4, 51)
+    lat[1], lat[3] = lat[0], lat[2]
+    ctx = weights.synth_context(cfg, 4, seed=52)
+    fused = eng.unet(lat, 500, ctx).clone()
+    seen = []
+
+    def identity(attn, is_cross, place, layer):
+        seen.append((tuple(attn.shape), is_cross, place, layer))
+
+    eng.set_attention_callback(identity, rows=4)
+    via_cb = eng.unet(lat, 500, ctx).clone()
+    eng.set_attention_callback(None)
+    assert len(seen) == 32 and [s[3] for s in seen] == list(range(32)) and [s[1] for s in seen] == [False, True] * 16
+    assert seen[0][0] == (4 * cfg.heads, 256, 256) and seen[1][0] == (4 * cfg.heads, 256, 77) and seen[12][2] == "mid"
+    assert rel(via_cb, fused) < 3e-3, rel(via_cb, fused)          # P rounded to fp16 at a different point than in the flash kernel
+    assert torch.equal(eng.unet(lat, 500, ctx), fused)            # the fused path is back
+
+    # (2) the oracle's edit controller as the callback vs the native descriptor for the same tables, first step of a 3-step schedule
+    prompts = ["a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate"]
+    tok = WordTokenizer()
+    steps = 3
+    c = ac.make_controller(SimpleNamespace(tokenizer=tok), prompts, True, {"default_": 0.4}, 0.6, None, {"words": ("square",), "values": (2,)},
+                           num_ddim_steps=steps)
+    tables = {"kind": "replace", "mapper": c.prev_controller.mapper[0], "equalizer": c.equalizer.reshape(-1),
+              "cross_alpha": c.cross_replace_alpha.reshape(steps + 1, 77), "self_range": c.num_self_replace, "lb": None}
+    dev_tables = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in tables.items()}
+    hook_gpu = po.EditController(32, dev_tables)
+    eng.set_attention_callback(lambda attn, is_cross, place, layer: hook_gpu(attn, is_cross, place), rows=4)
+    cb_edit = eng.unet(lat, 500, ctx).clone()
+    eng.set_attention_callback(None)
+    native_edit = eng.unet(lat, 500, ctx, rows_per_image=4, ctrls=[c.tables()], cur_step=0)
+    with torch.no_grad():
+        ref_edit = sd_oracle.unet_forward(usd, cfg, lat, 500, ctx, po.EditController(32, tables))
+    assert rel(cb_edit, ref_edit) < 4e-3, rel(cb_edit, ref_edit)
+    assert rel(cb_edit, native_edit) < 4e-3, rel(cb_edit, native_edit)
+    assert rel(fused[3], ref_edit[3]) > 3 * rel(cb_edit[3], ref_edit[3])          # the edit is visible in the target row
+
+    # (3) + (4) through the drop-in surface: register_attention_control(model, <object without .tables()>)
+    class HalveFirstKeys:                 # a user controller no descriptor can express
+        def __init__(self): self.calls = 0
+        def __call__(self, attn, is_cross, place):
+            self.calls += 1
+            if is_cross and place == "up":
+                attn = attn.clone()
+                attn[:, :, 1:4] *= 0.5
+            return attn
+
+    pipe = NativePipeline.__new__(NativePipeline)
+    from pnpinversion_amd.pipeline import NativeUNet
+    unet = NativeUNet(eng)
+    user = HalveFirstKeys()
+    ac.register_attention_control(SimpleNamespace(unet=unet), user)
+    got = unet(lat, 500, encoder_hidden_states=ctx)["sample"]
+    assert user.calls == 32
+    with torch.no_grad():
+        want = sd_oracle.unet_forward(usd, cfg, lat, 500, ctx, HalveFirstKeys())
+    assert rel(got, want) < 4e-3, rel(got, want)
+    ac.register_attention_control(SimpleNamespace(unet=unet), None)
+    assert torch.equal(unet(lat, 500, encoder_hidden_states=ctx)["sample"], fused)
+
+    class Boom:
+        def __call__(self, attn, is_cross, place): raise KeyError("boom")
+    ac.register_attention_control(SimpleNamespace(unet=unet), Boom())
+    with pytest.raises(KeyError, match="boom"):
+        unet(lat, 500, encoder_hidden_states=ctx)
+    ac.register_attention_control(SimpleNamespace(unet=unet), None)
+    assert torch.equal(unet(lat, 500, encoder_hidden_states=ctx)["sample"], fused)
+    with pytest.raises(TypeError, match="no native descriptor"):
+        ac.register_attention_control(SimpleNamespace(unet=unet), object())
+        unet(lat, 500, encoder_hidden_states=ctx)
+    ac.register_attention_control(SimpleNamespace(unet=unet), None)
+
+
 def test_vae_tiny(tiny):
     cfg, usd, vsd, eng = tiny
     g = torch.Generator().manual_seed(9)
