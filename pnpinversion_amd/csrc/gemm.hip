@@ -909,7 +909,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (cfg < 0 && g_use_table && dma_ok) {
     for (const TileEntry& e : kTileTable)
       if (e.M == p.M && e.N == p.N && e.K == p.K && e.ks == p.ksize) {
-        const int ebn = (e.cfg == 4 || e.cfg == 6) ? 320 : ((e.cfg == 5 || e.cfg == 7) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
+        const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12) ? 320 : ((e.cfg == 5 || e.cfg == 7) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
         const bool split_ok = e.split == 1 || (!p.geglu && ws && (size_t)e.split * p.M * p.N * sizeof(float) <= ws_bytes);
         const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
         if (split_ok && vt_ok && (g_wide || e.cfg < 4)) { cfg = e.cfg; split = e.split; }
@@ -961,11 +961,11 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     if (split > nchunks) split = nchunks;
     if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu || cfg == 3) split = 1;
   }
-  const bool c64 = cfg == 1 || cfg == 8 || cfg == 11, c256m = cfg == 3 || cfg == 6 || cfg == 7;
-  if (cfg_used) *cfg_used = split > 1 ? 2 : ((cfg >= 4 && cfg <= 7) ? 9 : (c64 ? 1 : 0));
+  const bool c64 = cfg == 1 || cfg == 8 || cfg == 11 || cfg == 12, c256m = cfg == 3 || cfg == 6 || cfg == 7;
+  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12) ? 9 : (c64 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
-  const int bn_sel = (cfg == 4 || cfg == 6) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (c64 ? 64 : 128));
+  const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (c64 ? 64 : 128));
   const bool vt_none = p.vt_col0 >= p.N;
   // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay
   // inside one batch item
@@ -1006,6 +1006,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
       case 12: r = launch_dma<128, 320, 32, 2, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
       default: r = launch_dma<128, 320, 32, 2>(p, grid, st, g_zero_page); break;      // 56 KB ring, two-pass epilogue, 2 blocks / CU
     }
+  } else if (cfg == 12) {
+    r = launch_dma<64, 320, 32, 2>(p, grid, st, g_zero_page);             // 64 x 320: 768 tiles on the 12-row 64 x 64 level = 3 per CU
+  } else if (cfg == 13) {
+    r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page);            // 32 KB ring (two-pass epilogue): 4 blocks / CU for the short-K layers
   } else if (cfg == 8) {
     r = launch_dma<64, 64, 64, 2, 2, 0, 4>(p, grid, st, g_zero_page);      // 16 waves: 4 k-groups
   } else if (cfg == 11) {

@@ -61,7 +61,7 @@ for (M, N, K, ks), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 tune(igemm_v320=v); res["320v%d" % v] = timeit(mk(4, 0), ncopy); tune(igemm_v320=1)
                 tune(igemm_v256n=v); res["256nv%d" % v] = timeit(mk(5, 0), ncopy); tune(igemm_v256n=1)
     if fast:
-        for name, c in (("64k4", 8), ("64k2", 11), ("128k2", 9), ("128k2b", 10)):
+        for name, c in (("64k4", 8), ("64k2", 11), ("128k2", 9), ("128k2b", 10), ("64x320", 12), ("128n2", 13)):
             res[name] = timeit(mk(c, 0), ncopy)
     nch = K // 64
     for sp in (2, 3, 4, 6, 8, 12, 16):
@@ -87,5 +87,5 @@ for (M, N, K, ks), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
 os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
 json.dump({"rows": rows_b, "shapes": res_all}, open(out_path, "w"), indent=0)
 ta = sum(r["us"]["auto"] * r["n_per_fwd"] for r in res_all); tb = sum(min(v for k, v in r["us"].items() if k != "auto") * r["n_per_fwd"] for r in res_all)
-t_old = sum(min(v for k, v in r["us"].items() if k != "auto" and not k.startswith(("320", "256", "64k", "128k"))) * r["n_per_fwd"] for r in res_all)
+t_old = sum(min(v for k, v in r["us"].items() if k != "auto" and not k.startswith(("320", "256", "64k", "128k", "64x", "128n"))) * r["n_per_fwd"] for r in res_all)
 print("sum over listed shapes per forward: auto %.2f ms, per-shape best %.2f ms, best without the wide tiles %.2f ms" % (ta / 1e3, tb / 1e3, t_old / 1e3))
