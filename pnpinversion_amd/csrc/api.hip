@@ -358,6 +358,7 @@ static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops, StatsReq* s
     // algorithmic HBM bytes: the input tensor(s) once, the weight once, the output once (+ the residual it adds)
     const double in_rows = (double)p.B * p.H * p.W;
     const double alg_bytes = 2.0 * (in_rows * (p.C1 + p.C2) + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.res ? 2.0 : 1.0));
+    igemm_last_launch(&pr.cfg, &pr.split);
     prof_close(c, pr, used, alg_flops, alg_bytes, p.M, p.N, p.K, p.ksize);
   } else {
     r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, nullptr, &srows);
@@ -1221,11 +1222,11 @@ int pnpi_profile_end(pnpi_ctx* c, pnpi_kernel_stats* out) {
   CKH(hipStreamSynchronize(c->st));
   if (const char* path = getenv("PNPI_PROFILE_DUMP")) {   // per-launch records for tools/ (class, M, N, K, ksize, us)
     if (FILE* f = fopen(path, "w")) {
-      fprintf(f, "cls,M,N,K,ksize,us,flops\n");
+      fprintf(f, "cls,M,N,K,ksize,us,flops,cfg,split\n");
       for (ProfRec& r : c->prof) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
-        fprintf(f, "%d,%d,%d,%d,%d,%.3f,%.0f\n", r.cls, r.M, r.N, r.K, r.ksize, ms * 1e3, r.flops);
+        fprintf(f, "%d,%d,%d,%d,%d,%.3f,%.0f,%d,%d\n", r.cls, r.M, r.N, r.K, r.ksize, ms * 1e3, r.flops, r.cfg, r.split);
       }
       fclose(f);
     }

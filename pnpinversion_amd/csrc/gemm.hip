@@ -839,6 +839,9 @@ static int g_use_table = 1;    // tuning "igemm_table" = 0: cost model only (no 
 static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in the store loop (fp16(fp16(acc + bias) + res)) instead of staged
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
+static int g_force_split = 0;   // > 0 with igemm_force_cfg: split-K of every auto-configured launch (in-forward tuning sweeps)
+static int g_last_cfg = -1, g_last_split = 1;   // what the most recent launch_igemm used (profiling dumps)
+void igemm_last_launch(int* cfg, int* split) { *cfg = g_last_cfg; *split = g_last_split; }
 static int g_force_cfg = -1;   // >= 0: every auto-configured launch uses this tile configuration (tests, whole-forward A/B)
 static int g_var128 = 2, g_var64 = 0, g_var256 = 0, g_var320 = 1, g_var256n = 1;
 static long g_v128_bk64_tiles = 0;   // PNPI_V128_BK64_TILES: tile count from which the 128x128 kernel switches to 128-byte rows   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
@@ -846,7 +849,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -905,7 +908,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   const long t64 = tiles_of(64, 64);
   int cfg = force_cfg;
   int split = 1;
-  if (cfg < 0 && g_force_cfg >= 0) cfg = g_force_cfg == 2 ? 1 : g_force_cfg;
+  if (cfg < 0 && g_force_cfg >= 0) { cfg = g_force_cfg == 2 ? 1 : g_force_cfg; if (force_split <= 0) force_split = g_force_split; }
   if (cfg < 0 && g_use_table && dma_ok) {
     for (const TileEntry& e : kTileTable)
       if (e.M == p.M && e.N == p.N && e.K == p.K && e.ks == p.ksize) {
@@ -965,6 +968,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12) ? 9 : (c64 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
+  g_last_cfg = cfg; g_last_split = split;
   const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (c64 ? 64 : 128));
   const bool vt_none = p.vt_col0 >= p.N;
   // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay
