@@ -10,6 +10,7 @@
 // global -> registers -> LDS staging (the conv gather needs per-lane predication, which LDS-DMA cannot do), LDS rows
 // padded by 16 B so that ds_read_b128 fragment reads are bank-conflict free (stride 144 B = 36 banks).
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #include "ops.h"
@@ -17,7 +18,7 @@
 static constexpr int BK = 64;
 static constexpr int LDS_LD = BK + 8;  // halfs
 
-__device__ __forceinline__ void epilogue_store4(const GemmP& p, int m, int nb, const float* v) {
+__device__ __forceinline__ void epilogue_store4(const GemmP& p, int m, int nb, const float* v, const float* bias) {
   if (m >= p.M) return;
   float o[4];
 #pragma unroll
@@ -25,7 +26,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, int m, int nb, c
     int n = nb + j;
     float x = v[j] * p.alpha;
     if (n < p.N) {
-      if (p.bias) x += p.bias[n];
+      if (bias) x += bias[n];
       if (p.res) x += (float)p.res[(size_t)m * p.ldres + n];
     }
     o[j] = x;
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
               if (nb + j < p.N) dst[j] = v[j];
           }
         } else {
-          epilogue_store4(p, m, nb, v);
+          epilogue_store4(p, m, nb, v, p.bias);
         }
       }
     }
@@ -493,13 +494,36 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
     else if (is_c0 == p.C1) retap = true;
   };
 
+  // Accumulators.  With alpha == 1 the bias is the accumulator's INITIAL value (p.bias_init, set by the launcher): 4 * NI
+  // unconditional 16-byte loads per lane, issued before the first DMA instruction and landed long before the first MFMA needs
+  // them -- instead of 16 * MI * NI dependent 4-byte loads in the epilogue, each with its own wait, which cost the short-K
+  // layers (10 ... 40 k-chunks per tile) more than their whole main loop.  A lane holds columns n .. n + 3 of every 8-column
+  // group, the same for every mi.
   floatx16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  const float* ebias = p.bias_init ? nullptr : p.bias;   // what the epilogue still has to add
+  if (p.bias_init && kgrp == 0) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+        floatx4 b = *reinterpret_cast<const floatx4*>(p.bias + min(n, p.N - 4));   // N % 4 == 0: a group is all in or all out
+        if (n >= p.N) b = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][ni][4 * g + j] = b[j];
+      }
+#pragma unroll
+    for (int mi = 1; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[0][ni];
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  }
 
   // fragment read addressing (same involution as the DMA source permutation)
   const int lr = lane & 31, hk = lane >> 5;
@@ -616,12 +640,16 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
       const int r0 = e * EROWS;                         // first tile row of this pass
       const bool res_staged = p.res && !p.res_late;
       if (res_staged) {
-        if (s_active)
+        if (s_active) {
+          // clamped addresses instead of predicated loads: the loads of an unrolled group issue back to back (rows past M / columns
+          // past N stage finite junk that is never stored)
+          const int nres = min(n0 + sv * 8, p.N - 8);
+#pragma unroll 8
           for (int r = sg; r < EROWS; r += G) {
-            const int m = m0 + r0 + r, n = n0 + sv * 8;
-            half8 val = (m < p.M && n < p.N) ? ldg_half8(p.res + (size_t)m * p.ldres + n) : zero_half8();
-            *reinterpret_cast<half8*>(sOut + r * OLD + sv * 8) = val;
+            const int m = min(m0 + r0 + r, p.M - 1);
+            *reinterpret_cast<half8*>(sOut + r * OLD + sv * 8) = ldg_half8(p.res + (size_t)m * p.ldres + nres);
           }
+        }
         __syncthreads();
       }
       if (tr_tile) {
@@ -640,7 +668,7 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                   float o = acc[mi][ni][4 * g + j] * p.alpha;
-                  if (p.bias && n0 + nl + j < p.N) o += p.bias[n0 + nl + j];
+                  if (ebias && n0 + nl + j < p.N) o += ebias[n0 + nl + j];
                   sOut[(nl + j) * TOLD + ml] = (half_t)o;
                 }
               }
@@ -662,42 +690,50 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
         continue;
       }
       if (EPASS == 1 || (wave >> 1) == e) {
+        // two copies, selected by a block-uniform branch: with the bias already in the accumulators (the usual case) the staging
+        // loop has no per-element control flow at all
+        auto stage = [&](auto has_bias) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int ml = wm0 - r0 + mi * 32 + (lane & 31);
+          for (int mi = 0; mi < MI; ++mi) {
+            const int ml = wm0 - r0 + mi * 32 + (lane & 31);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
+              half4* slot0 = reinterpret_cast<half4*>(sOut + ml * OLD + wn0 + ni * 32 + 4 * (lane >> 5));   // slot of group g: + 2 * g
+              half4 r4[4];
+              if (res_staged) {                  // the four residual slots of this 32-column tile in flight together
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
-              const int n = n0 + nl;
-              half4* slot = reinterpret_cast<half4*>(sOut + ml * OLD + nl);
-              float o[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                o[j] = acc[mi][ni][4 * g + j] * p.alpha;
-                if (p.bias && n + j < p.N) o[j] += p.bias[n + j];
+                for (int g = 0; g < 4; ++g) r4[g] = slot0[2 * g];
               }
-              if (res_staged) {
-                half4 r4 = *slot;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] += (float)r4[j];
+              for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  o[j] = acc[mi][ni][4 * g + j] * p.alpha;
+                  if constexpr (decltype(has_bias)::value) { if (n + j < p.N) o[j] += ebias[n + j]; }
+                }
+                if (res_staged) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) o[j] += (float)r4[g][j];
+                }
+                half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                slot0[2 * g] = h4;
               }
-              half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-              *slot = h4;
             }
           }
-        }
+        };
+        if (ebias) stage(std::true_type{}); else stage(std::false_type{});
       }
       __syncthreads();
       if (!p.geglu) {
-        if (s_active) {
-          const int n = n0 + sv * 8;
+        const int n = n0 + sv * 8;
+        if (s_active && n < p.N) {
 #pragma unroll 4
           for (int r = sg; r < EROWS; r += G) {
             const int m = m0 + r0 + r;
-            if (m < p.M && n < p.N) {
-              half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + sv * 8);
+            half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + sv * 8);
+            if (m < p.M) {
               if (p.res && p.res_late) {   // residual added on the way out (coalesced 16-byte reads, no staging pass / barrier)
                 const half8 rv = ldg_half8(p.res + (size_t)m * p.ldres + n);
 #pragma unroll
@@ -775,7 +811,7 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
             }
           }
         } else {
-          epilogue_store4(p, m, nb, v);
+          epilogue_store4(p, m, nb, v, ebias);
         }
       }
     }
@@ -817,7 +853,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmP p) {
       for (int j = 0; j < 4; ++j)
         if (nb + j < p.N) v[j] += src[j];
     }
-    epilogue_store4(p, m, nb, v);
+    epilogue_store4(p, m, nb, v, p.bias);
   }
 }
 
@@ -826,7 +862,7 @@ void gemm_defaults(GemmP& p) {
   p.B = 1; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.ksize = 1; p.stride = 1; p.pad = 0; p.ups = 0;
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
   p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1;
-  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr; p.res_late = 0;
+  p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr; p.res_late = 0; p.bias_init = 0;
 }
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
@@ -839,6 +875,7 @@ static int g_use_table = 1;    // tuning "igemm_table" = 0: cost model only (no 
 static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in the store loop (fp16(fp16(acc + bias) + res)) instead of staged
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
+static int g_bias_init = 1;     // 0: bias added in the epilogue (ablation)
 static int g_force_split = 0;   // > 0 with igemm_force_cfg: split-K of every auto-configured launch (in-forward tuning sweeps)
 static int g_last_cfg = -1, g_last_split = 1;   // what the most recent launch_igemm used (profiling dumps)
 void igemm_last_launch(int* cfg, int* split) { *cfg = g_last_cfg; *split = g_last_split; }
@@ -849,7 +886,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -978,6 +1015,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.epi_lds = (vt_none || vt_lds) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
   if (vt_lds) p.stats = nullptr;
   p.res_late = g_res_late;
+  p.bias_init = (dma_ok && split == 1 && p.bias && p.alpha == 1.f && p.N % 4 == 0 && ((uintptr_t)p.bias & 15) == 0 && g_bias_init) ? 1 : 0;
   if (p.geglu && !(p.epi_lds && dma_ok && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
   const int bm = c256m ? 256 : (c64 ? 64 : 128);

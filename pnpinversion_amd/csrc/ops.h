@@ -26,6 +26,7 @@ struct GemmP {
   float* stats;   // optional: per (m-tile, channel) sum / sum-of-squares of the fp16 output, [gridDim.x][N][2] (GroupNorm fusion)
   int geglu;      // N columns are [x(32) | gate(32)] interleaved groups; output has N/2 columns: x * gelu(gate)
   int epi_lds;    // set by launch_igemm: coalesced LDS-staged epilogue is applicable
+  int bias_init;  // set by launch_igemm: the LDS-DMA kernel starts its accumulators at the bias (alpha == 1, no split-K) and its epilogue adds none
   int res_late;   // set by launch_igemm: the LDS epilogue adds the residual in its store loop instead of staging it
   int gx, gy, gz, tile_order;   // set by the launcher: logical tile grid and XCD-aware traversal order (see igemm_dma_kernel)
 };
