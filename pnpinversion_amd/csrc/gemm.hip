@@ -857,6 +857,32 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmP p) {
   }
 }
 
+// The same combine for the layouts every layer of the UNet has (N % 4 == 0, plain row-major output, 16-byte aligned bias, 8-byte
+// aligned rows): one thread per 4 columns, unconditional 16-byte slab loads unrolled over the slabs (the generic kernel's
+// predicated scalar loads each carry their own wait), same summation order -> same bits.
+__global__ void __launch_bounds__(256) splitk_reduce_vec_kernel(GemmP p) {
+  const int gpr = p.N >> 2;
+  const size_t total = (size_t)p.M * gpr;
+  const size_t slab_stride = (size_t)p.M * p.N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / gpr);
+    const int nb = (int)(idx - (size_t)m * gpr) * 4;
+    const float* src = p.slab + (size_t)m * p.N + nb;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int z = 0; z < p.splitk; ++z) v += *reinterpret_cast<const floatx4*>(src + (size_t)z * slab_stride);
+    v *= p.alpha;
+    if (p.bias) v += *reinterpret_cast<const floatx4*>(p.bias + nb);
+    if (p.res) {
+      const half4 r4 = *reinterpret_cast<const half4*>(p.res + (size_t)m * p.ldres + nb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += (float)r4[j];
+    }
+    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4*>(p.out + (size_t)m * p.ldo + nb) = h;
+  }
+}
+
 void gemm_defaults(GemmP& p) {
   p.x1 = nullptr; p.x2 = nullptr; p.C1 = 0; p.C2 = 0; p.ldx1 = 0; p.ldx2 = 0;
   p.B = 1; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.ksize = 1; p.stride = 1; p.pad = 0; p.ups = 0;
@@ -929,7 +955,8 @@ struct TileEntry { int M, N, K, ks, cfg, split; };
 static const TileEntry kTileTable[] = {
 #include "tile_table.inc"
 };
-// experimental 8-wave tiles (cfg 6 = 256x320, cfg 7 = 256x256; 128-byte rows, two stages, one block per CU): force_cfg only
+// cfg 6 = 256x320, 7 = 256x256 (8 waves, 128-byte rows, two stages, one block per CU); 8-11: K-parallel wave groups; 12 = 64x320;
+// 13 = 128x128 with a two-stage ring; 14 / 15 = 128x128 / 128x256 with 128-byte rows: reached through the table or force_cfg
 
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used,
                  int* stats_tile_rows) {
@@ -949,10 +976,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (cfg < 0 && g_use_table && dma_ok) {
     for (const TileEntry& e : kTileTable)
       if (e.M == p.M && e.N == p.N && e.K == p.K && e.ks == p.ksize) {
-        const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12) ? 320 : ((e.cfg == 5 || e.cfg == 7) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
+        const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12) ? 320 : ((e.cfg == 5 || e.cfg == 7 || e.cfg == 15) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
         const bool split_ok = e.split == 1 || (!p.geglu && ws && (size_t)e.split * p.M * p.N * sizeof(float) <= ws_bytes);
         const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
-        if (split_ok && vt_ok && (g_wide || e.cfg < 4)) { cfg = e.cfg; split = e.split; }
+        if (split_ok && vt_ok && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14)) { cfg = e.cfg; split = e.split; }
         break;
       }
   }
@@ -1002,11 +1029,11 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu || cfg == 3) split = 1;
   }
   const bool c64 = cfg == 1 || cfg == 8 || cfg == 11 || cfg == 12, c256m = cfg == 3 || cfg == 6 || cfg == 7;
-  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12) ? 9 : (c64 ? 1 : 0));
+  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12 || cfg == 15) ? 9 : (c64 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   g_last_cfg = cfg; g_last_split = split;
-  const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12) ? 320 : ((cfg == 5 || cfg == 7) ? 256 : (c64 ? 64 : 128));
+  const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12) ? 320 : ((cfg == 5 || cfg == 7 || cfg == 15) ? 256 : (c64 ? 64 : 128));
   const bool vt_none = p.vt_col0 >= p.N;
   // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay
   // inside one batch item
@@ -1052,6 +1079,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     r = launch_dma<64, 320, 32, 2>(p, grid, st, g_zero_page);             // 64 x 320: 768 tiles on the 12-row 64 x 64 level = 3 per CU
   } else if (cfg == 13) {
     r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page);            // 32 KB ring (two-pass epilogue): 4 blocks / CU for the short-K layers
+  } else if (cfg == 14) {
+    r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page);            // 128-byte rows, half the barriers per k: 64 KB, 2 blocks / CU
+  } else if (cfg == 15) {
+    r = launch_dma<128, 256, 64, 2>(p, grid, st, g_zero_page);            // the same for the 128 x 256 tile: 96 KB, 1 block / CU
   } else if (cfg == 8) {
     r = launch_dma<64, 64, 64, 2, 2, 0, 4>(p, grid, st, g_zero_page);      // 16 waves: 4 k-groups
   } else if (cfg == 11) {
@@ -1106,7 +1137,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     size_t total = (size_t)p.M * ((p.N + 3) / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    splitk_reduce_kernel<<<blocks, 256, 0, st>>>(p);
+    const bool vec = p.N % 4 == 0 && p.vt_col0 >= p.N && p.ldo % 4 == 0 && (!p.res || p.ldres % 4 == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                     ((uintptr_t)p.out & 7) == 0 && (!p.res || ((uintptr_t)p.res & 7) == 0) && ((uintptr_t)ws & 15) == 0;
+    if (vec) splitk_reduce_vec_kernel<<<blocks, 256, 0, st>>>(p);
+    else splitk_reduce_kernel<<<blocks, 256, 0, st>>>(p);
   }
   return (int)hipGetLastError();
 }

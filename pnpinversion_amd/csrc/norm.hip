@@ -270,12 +270,22 @@ __global__ void __launch_bounds__(256) gn_finalize_tiles_kernel(const float* __r
   const int C = C1 + C2, cpg = C / G;
   const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   float s = 0.f, q = 0.f;
-  for (int cl = 0; cl < cpg; ++cl) {
-    const int c = g * cpg + cl;
-    const float* st; int cs, cc, tpb;
-    if (c < C1) { st = st1; cs = C1; cc = c; tpb = tpb1; } else { st = st2; cs = C2; cc = c - C1; tpb = tpb2; }
-    const float* base = st + ((size_t)b * tpb * cs + cc) * 2;
-    for (int t = tid; t < tpb; t += 256) { s += base[(size_t)t * cs * 2]; q += base[(size_t)t * cs * 2 + 1]; }
+  // the group's (channel, m-tile) partial pairs of each source spread over all 256 threads (8-byte loads, channels fastest: coalesced),
+  // fixed thread -> pair assignment and a fixed combine tree: deterministic
+  const int cg0 = g * cpg, cg1 = cg0 + cpg;
+  {
+    const int a0 = min(cg0, C1), n1 = min(cg1, C1) - a0;
+    for (int i = tid; i < n1 * tpb1; i += 256) {
+      const int t = i / n1, cl = i - t * n1;
+      const float2 v = *reinterpret_cast<const float2*>(st1 + (((size_t)b * tpb1 + t) * C1 + a0 + cl) * 2);
+      s += v.x; q += v.y;
+    }
+    const int b0 = max(cg0, C1) - C1, n2 = max(cg1, C1) - C1 - b0;
+    for (int i = tid; i < n2 * tpb2; i += 256) {
+      const int t = i / n2, cl = i - t * n2;
+      const float2 v = *reinterpret_cast<const float2*>(st2 + (((size_t)b * tpb2 + t) * C2 + b0 + cl) * 2);
+      s += v.x; q += v.y;
+    }
   }
   s = wave_sum(s); q = wave_sum(q);
   if ((tid & 63) == 0) { s_s[tid >> 6] = s; s_q[tid >> 6] = q; }
@@ -404,57 +414,82 @@ int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, i
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wavefront per token row; the row stays in registers (C <= 2048) so mean and variance are two exact passes.
+// A wavefront owns RPW token rows at once; the rows stay in registers (C <= 2048) so mean and variance are two exact passes.
+// VPL = 16-byte vectors per lane and row.  One row per wave (640 bytes at C = 320) left a single load in flight per lane and the
+// kernel latency-bound at a quarter of the HBM rate; with RPW * VPL loads issued back to back (clamped addresses instead of
+// predication, masked lanes zeroed afterwards) and RPW independent reduction chains the same arithmetic runs per row -- the
+// per-lane and cross-lane summation order is unchanged, so the output bits are too.
+template <int VPL, int RPW>
 __global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict__ x, int M, int C, float eps,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         half_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= M) return;
   const int C8 = C >> 3;
-  half8 v[4];
-  float s = 0.f;
+  half8 v[RPW][VPL];
+  bool ok[VPL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int cv = lane + 64 * i;
-    if (cv < C8) {
-      v[i] = ldg_half8(x + (size_t)row * C + cv * 8);
+  for (int i = 0; i < VPL; ++i) ok[i] = lane + 64 * i < C8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
-    }
+  for (int r = 0; r < RPW; ++r) {
+    const half_t* src = x + (size_t)min(row0 + r, M - 1) * C;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[r][i] = ldg_half8(src + min(lane + 64 * i, C8 - 1) * 8);
   }
-  s = wave_sum(s);
-  const float mean = s / (float)C;
-  float q = 0.f;
+  float s[RPW], q[RPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int cv = lane + 64 * i;
-    if (cv < C8) {
+  for (int r = 0; r < RPW; ++r) {
+    s[r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
-    }
+    for (int i = 0; i < VPL; ++i)
+      if (ok[i]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[r] += (float)v[r][i][j];
+      }
   }
-  q = wave_sum(q);
-  const float rstd = rsqrtf(q / (float)C + eps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int cv = lane + 64 * i;
-    if (cv < C8) {
+  for (int r = 0; r < RPW; ++r) s[r] = wave_sum(s[r]);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const float mean = s[r] / (float)C;
+    s[r] = mean;
+    q[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if (ok[i]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float d = (float)v[r][i][j] - mean; q[r] += d * d; }
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) q[r] = wave_sum(q[r]);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (!ok[i]) continue;
+    const int c0 = (lane + 64 * i) * 8;
+    float ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if (row0 + r >= M) continue;
+      const float mean = s[r], rstd = rsqrtf(q[r] / (float)C + eps);
       half8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int c = cv * 8 + j;
-        o[j] = (half_t)(((float)v[i][j] - mean) * rstd * gamma[c] + beta[c]);
-      }
-      *reinterpret_cast<half8*>(out + (size_t)row * C + cv * 8) = o;
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[r][i][j] - mean) * rstd * ga[j] + be[j]);
+      *reinterpret_cast<half8*>(out + (size_t)(row0 + r) * C + c0) = o;
     }
   }
 }
 
 int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamma, const float* beta, half_t* out,
                      hipStream_t st) {
-  if ((C & 7) || C > 2048) return -3;
-  layernorm_kernel<<<(M + 3) / 4, 256, 0, st>>>(x, M, C, eps, gamma, beta, out);
+  if ((C & 7) || C > 2048 || M <= 0) return -3;
+  const int C8 = C >> 3;
+  if (C8 <= 64) layernorm_kernel<1, 4><<<(M + 15) / 16, 256, 0, st>>>(x, M, C, eps, gamma, beta, out);
+  else if (C8 <= 128) layernorm_kernel<2, 2><<<(M + 7) / 8, 256, 0, st>>>(x, M, C, eps, gamma, beta, out);
+  else layernorm_kernel<4, 1><<<(M + 3) / 4, 256, 0, st>>>(x, M, C, eps, gamma, beta, out);
   return (int)hipGetLastError();
 }
 

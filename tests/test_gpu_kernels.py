@@ -40,6 +40,7 @@ def h16(*shape, scale=1.0, seed=0):
     (256, 320, 2880, 8, 0), (130, 70, 200, 8, 0), (64, 1280, 11520, 8, 3), (300, 192, 640, 11, 0),   # 64x64 tile, 4 / 2 k-groups of waves
     (768, 1280, 1280, 9, 0), (200, 130, 96, 9, 0), (512, 256, 4096, 10, 2), (128, 128, 64, 10, 0),   # 128x128 tile, 2 k-groups
     (1000, 640, 640, 12, 0), (100, 300, 128, 12, 0), (512, 320, 2048, 12, 2), (700, 384, 320, 13, 0),  # 64x320 tile; 128x128 two-stage
+    (700, 384, 320, 14, 0), (512, 256, 4096, 14, 3), (1000, 768, 320, 15, 0), (77, 520, 192, 15, 0),   # 128-byte-row variants of 128x128 / 128x256
 ])
 def test_gemm(ctx, M, N, K, cfg, split):
     a = h16(M, K, seed=1)
@@ -74,7 +75,7 @@ def test_gemm_wide_tile_variants(ctx, key, val, cfg):
 
 
 @pytest.mark.parametrize("cfg,N,v320", [(0, 320, 0), (1, 192, 0), (4, 320, 0), (4, 640, 1), (5, 512, 0), (5, 256, 1), (6, 320, 0), (7, 256, 0),
-                                        (8, 192, 1), (9, 256, 1), (12, 320, 1), (13, 256, 1)])
+                                        (8, 192, 1), (9, 256, 1), (12, 320, 1), (13, 256, 1), (14, 256, 1), (15, 512, 1)])
 def test_conv_epilogue_groupnorm_statistics(ctx, cfg, N, v320):
     """The per-(m-tile, channel) sum / sum-of-squares partials a conv epilogue hands to the consumer GroupNorm: fp32 sums of the
     STORED fp16 values, every tile configuration (incl. the two-pass epilogue of the 2-stage wide tiles), ragged last m-tile."""
@@ -278,7 +279,7 @@ def test_geglu(ctx):
     assert rel_err(out, a * F.gelu(g)) < 2e-3
 
 
-@pytest.mark.parametrize("force", [-1, 0, 1, 4, 5, 6, 8, 9, 12, 13])
+@pytest.mark.parametrize("force", [-1, 0, 1, 4, 5, 6, 8, 9, 12, 13, 14, 15])
 @pytest.mark.parametrize("M,K,I", [(4096, 320, 1280), (1024, 640, 2560), (200, 1280, 5120), (64, 64, 64)])
 def test_gemm_fused_geglu(ctx, M, K, I, force):
     """GEGLU.forward (my_diffusers/models/attention.py:331-333): proj -> chunk -> x * gelu(gate), fused into the GEMM epilogue
