@@ -482,6 +482,9 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   half_t* qk = talloc(c, (size_t)M * 2 * hd);
   const int ldv = round_up_i(N, 8);
   half_t* vt = talloc(c, (size_t)B * hd * ldv);
+  // call-back path: P V runs over the padded key count, so the pad columns of V^T must be zeros -- cleared BEFORE the projection fills
+  // the real columns (only the 2 x 2 level of the narrow test configurations has a token count that is not a multiple of 8)
+  if (c->attn_cb && !c->dry && ldv != N) CKH(hipMemsetAsync(vt, 0, (size_t)B * hd * ldv * sizeof(half_t), c->st));
   {
     VtOut v; v.outT = vt; v.col0 = 2 * hd; v.ld = ldv; v.f32 = 0; v.rpb = N;
     CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qk, 2 * hd, 1.f, &v, 2.0 * M * 3.0 * C * C));
@@ -495,7 +498,6 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     a.rows = rep ? cd.rows_rep : (masa ? cd.rows_masa : cd.rows_id); a.nrows = B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
     if (c->attn_cb && !c->dry) {
-      if (ldv != N) CKH(hipMemsetAsync(vt, 0, (size_t)B * hd * ldv * sizeof(half_t), c->st));   // (never: token counts are multiples of 8)
       CKP(attn_materialized(c, qk, 2 * hd, 0, qk, 2 * hd, hd, vt, ldv, ao, C, t.heads, N, N, t.Dp, t.dh, scale, B, 0, t.place, 2 * block_index));
     } else if (!c->dry) PROFD(PNPI_KC_ATTN_FLASH, 4.0 * B * t.heads * (double)N * N * t.dh, 0.0, N, N, t.Dp, launch_attn_flash(a, c->st));
   }
@@ -1051,6 +1053,7 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
     c->bias_valid.assign(g.n_train_timesteps, 0);
     c->tkv.cap = text_kv_bytes(c, max_unet_rows);
     CKH(hipMalloc((void**)&c->tkv.base, c->tkv.cap));
+    CKH(hipMemset(c->tkv.base, 0, c->tkv.cap));   // the V^T rows are padded to 8 keys: the pad columns stay zero (call-back path multiplies them by zero probabilities)
   }
   // sinusoidal timestep table, get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0), fp64 -> fp32
   // (my_diffusers/models/embeddings.py:21-60)
