@@ -358,7 +358,7 @@ static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops, StatsReq* s
     // algorithmic HBM bytes: the input tensor(s) once, the weight once, the output once (+ the residual it adds)
     const double in_rows = (double)p.B * p.H * p.W;
     const double alg_bytes = 2.0 * (in_rows * (p.C1 + p.C2) + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.res ? 2.0 : 1.0));
-    igemm_last_launch(&pr.cfg, &pr.split);
+    igemm_last_launch(&pr.cfg, &pr.split, pr.geom);
     prof_close(c, pr, used, alg_flops, alg_bytes, p.M, p.N, p.K, p.ksize);
   } else {
     r = launch_igemm(p, c->splitk_ws, c->splitk_bytes, c->st, -1, 0, nullptr, &srows);
@@ -1225,11 +1225,14 @@ int pnpi_profile_end(pnpi_ctx* c, pnpi_kernel_stats* out) {
   CKH(hipStreamSynchronize(c->st));
   if (const char* path = getenv("PNPI_PROFILE_DUMP")) {   // per-launch records for tools/ (class, M, N, K, ksize, us)
     if (FILE* f = fopen(path, "w")) {
-      fprintf(f, "cls,M,N,K,ksize,us,flops,cfg,split\n");
+      fprintf(f, "cls,M,N,K,ksize,us,flops,cfg,split,kernel,bytes\n");
       for (ProfRec& r : c->prof) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
-        fprintf(f, "%d,%d,%d,%d,%d,%.3f,%.0f,%d,%d\n", r.cls, r.M, r.N, r.K, r.ksize, ms * 1e3, r.flops, r.cfg, r.split);
+        char kn[96] = "-";     // the kernel template a rocprofv3 kernel trace shows for this launch
+        if (r.geom[0]) snprintf(kn, sizeof kn, "igemm_dma_kernel<%d %d %d %d %d %d %d>", r.geom[0], r.geom[1], r.geom[2], r.geom[3], r.geom[4], r.geom[5], r.geom[6]);
+        else if (r.cfg >= 0) snprintf(kn, sizeof kn, "igemm_kernel");
+        fprintf(f, "%d,%d,%d,%d,%d,%.3f,%.0f,%d,%d,%s,%.0f\n", r.cls, r.M, r.N, r.K, r.ksize, ms * 1e3, r.flops, r.cfg, r.split, kn, r.bytes);
       }
       fclose(f);
     }

@@ -818,9 +818,11 @@ igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
   }
 }
 
+static int g_last_geom[7] = {0, 0, 0, 0, 0, 0, 0};   // template arguments of the most recent igemm_dma_kernel launch (all 0: the v1 kernel)
 template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
 static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t* zero_page) {
   using GEO = IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>;
+  g_last_geom[0] = BM; g_last_geom[1] = BN; g_last_geom[2] = BKT; g_last_geom[3] = NST; g_last_geom[4] = WGM; g_last_geom[5] = ABL; g_last_geom[6] = WK;
   GemmP p = p_in;
   p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
   {
@@ -904,7 +906,7 @@ static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings w
 static int g_bias_init = 1;     // 0: bias added in the epilogue (ablation)
 static int g_force_split = 0;   // > 0 with igemm_force_cfg: split-K of every auto-configured launch (in-forward tuning sweeps)
 static int g_last_cfg = -1, g_last_split = 1;   // what the most recent launch_igemm used (profiling dumps)
-void igemm_last_launch(int* cfg, int* split) { *cfg = g_last_cfg; *split = g_last_split; }
+void igemm_last_launch(int* cfg, int* split, int* geom) { *cfg = g_last_cfg; *split = g_last_split; for (int i = 0; i < 7; ++i) geom[i] = g_last_geom[i]; }
 static int g_force_cfg = -1;   // >= 0: every auto-configured launch uses this tile configuration (tests, whole-forward A/B)
 static int g_var128 = 2, g_var64 = 0, g_var256 = 0, g_var320 = 1, g_var256n = 1;
 static long g_v128_bk64_tiles = 0;   // PNPI_V128_BK64_TILES: tile count from which the 128x128 kernel switches to 128-byte rows   // tuning variants (PNPI_IGEMM_V128 / PNPI_IGEMM_V64)
@@ -1033,6 +1035,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   g_last_cfg = cfg; g_last_split = split;
+  for (int i = 0; i < 7; ++i) g_last_geom[i] = 0;
   const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12) ? 320 : ((cfg == 5 || cfg == 7 || cfg == 15) ? 256 : (c64 ? 64 : 128));
   const bool vt_none = p.vt_col0 >= p.N;
   // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay

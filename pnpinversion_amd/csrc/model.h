@@ -158,7 +158,7 @@ struct TextKV {
   bool use = false;               // the forward in flight reads the cache instead of projecting the context
 };
 
-struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; int M, N, K, ksize; int cfg = -1, split = 0; };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; int M, N, K, ksize; int cfg = -1, split = 0; int geom[7] = {0, 0, 0, 0, 0, 0, 0}; };
 
 struct pnpi_ctx {
   pnpi_model_config cfg;

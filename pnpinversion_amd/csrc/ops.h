@@ -36,7 +36,8 @@ void gemm_defaults(GemmP& p);
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0,
                  int* cfg_used = nullptr, int* stats_tile_rows = nullptr);
 int igemm_init();  // sets dynamic-LDS attributes once
-void igemm_last_launch(int* cfg, int* split);         // tile configuration / split-K of the most recent launch_igemm (profiling)
+// tile configuration id / split-K of the most recent launch_igemm and the <BM, BN, BKT, NST, WGM, ABL, WK> of its igemm_dma_kernel (profiling)
+void igemm_last_launch(int* cfg, int* split, int* geom7);
 int igemm_set_tuning(const char* key, int value);   // process-wide tuning knobs; 0 on success, -1 unknown key
 void igemm_set_dma(int on);  // 1 (default): LDS-DMA kernel where applicable; 0: register-staged v1 kernel everywhere
 
