@@ -292,13 +292,18 @@ def main():
         # this same command, reduced by tools/pmc_summary.py (gfx950 correction applied there) and committed under profiles/.
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_traffic.json")
         if roofline is not None and os.path.exists(pmc):
-            tag = roofline["kernel"].replace(" ", "")           # igemm_dma_kernel<128,128,32,3,2,0,1>
+            tag = roofline["kernel"].replace(" ", "")           # igemm_dma_kernel<128,128,64,2,2,0,1>
             for name, v in json.load(open(pmc))["kernels"].items():
-                if tag in name.replace(" ", ""):
+                if v.get("template") == tag:
+                    # counters were collected on the 12-row forwards of the lock-step loop (tools/profile_pmc.sh), so the algorithmic bytes
+                    # to compare with are those of the same launches, not this run's mix of 1-row and 12-row launches
                     roofline["traffic"] = v["traffic_bytes"]
+                    roofline["traffic_alg_bytes_same_launches"] = v.get("alg_bytes_per_launch")
+                    roofline["traffic_over_alg"] = v.get("traffic_over_alg")
                     if "mfma_util" in v:
                         roofline["mfma_busy"] = v["mfma_util"]
-                    roofline["traffic_source"] = "profiles/round2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, mean per launch)"
+                    roofline["traffic_source"] = ("profiles/round2_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of 12-row "
+                                                  "UNet forwards (tools/fwd_only.py), mean per launch of this kernel")
                     break
         n_img = args.steps * world
         per_rank_flops = executed_flops(ctr)
