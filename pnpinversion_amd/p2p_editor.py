@@ -243,6 +243,12 @@ class P2PEditor:
         (inversion.py:375-391), the AttentionStore reconstruction pass and the edit pass (p2p_guidance_forward.py:135-173) walk
         the same 50 timesteps and only exchange noise_loss[i] at step i, so they run as ONE 12-row UNet launch per step."""
         model = self.ldm_stable
+        x_stars = self._invert_stage(model, inv, image_gt, prompts, inverse_guidance_scale)
+        return self._edit_stage(x_stars, inv.context, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
+                                self_replace_steps, blend_word, eq_params, is_replace_controller, add_target, return_stages, side, offset_scale)
+
+    def _invert_stage(self, model, inv, image_gt, prompts, inverse_guidance_scale=None):
+        """Stage 1 of an edit on `model`: prompt embedding, VAE encode (+ the reference's discarded decode), the 50 one-row inversion steps."""
         model.scheduler.set_timesteps(self.num_ddim_steps)
         inv.init_prompt(prompts)
         register_attention_control(model, None)
@@ -250,6 +256,13 @@ class P2PEditor:
             _, x_stars = inv.ddim_inversion(image_gt)
         else:
             _, x_stars = inv.ddim_with_guidance_scale_inversion(image_gt, inverse_guidance_scale)
+        return x_stars
+
+    def _edit_stage(self, x_stars, context, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps, self_replace_steps,
+                    blend_word, eq_params, is_replace_controller, add_target, return_stages, side, offset_scale=None):
+        """Stage 2 on the main pipeline: the lock-step (or pruned) loop from the inversion trajectory, the decodes, the panel."""
+        model = self.ldm_stable
+        model.scheduler.set_timesteps(self.num_ddim_steps)
         controller = make_controller(pipeline=model, prompts=prompts, is_replace_controller=is_replace_controller,
                                      cross_replace_steps={"default_": cross_replace_steps}, self_replace_steps=self_replace_steps,
                                      blend_words=blend_word, equilizer_params=eq_params, num_ddim_steps=self.num_ddim_steps,
@@ -258,7 +271,7 @@ class P2PEditor:
         if self.schedule == "pruned":
             if add_target or offset_scale is not None:
                 raise NotImplementedError("the pruned schedule is the plain directinversion+p2p edit (full offset on the source row only)")
-            out = model.engine.direct_edit_pruned(torch.stack(x_stars), inv.context[None], [controller.tables()],
+            out = model.engine.direct_edit_pruned(torch.stack(list(x_stars)), context[None], [controller.tables()],
                                                   model.scheduler.timesteps.numpy(), guidance_scale)
             controller.cur_step += self.num_ddim_steps
             image_instruct = txt_draw(f"source prompt: {prompt_src}\ntarget prompt: {prompt_tar}", target_size=(side, side))
@@ -266,7 +279,7 @@ class P2PEditor:
             latents = out[0]
             reconstruct_latent = torch.stack([out[0, 0], out[0, 0]])   # the reconstruction pass only reproduces x*_0 (Note D i)
         else:
-            nl, lats = model.engine.direct_edit(torch.stack(x_stars), inv.context[None], [None, [controller.tables()]],
+            nl, lats = model.engine.direct_edit(torch.stack(list(x_stars)), context[None], [None, [controller.tables()]],
                                                 model.scheduler.timesteps.numpy(), guidance_scale, offset_rows=2 if add_target else 1,
                                                 offset_scale=offset_scale)
             controller.cur_step += self.num_ddim_steps
@@ -281,6 +294,61 @@ class P2PEditor:
             return panel, dict(x_stars=x_stars, noise_loss_list=noise_loss_list, reconstruct_latent=reconstruct_latent,
                                latents=latents, reconstruct_image=reconstruct_image, edited_image=images[-1])
         return panel
+
+    def _second_pipeline(self):
+        """A second library context on its own HIP stream with a copy of the packed weight arena (2 GB of 288): the inversion of
+        the NEXT image runs there while this image's lock-step loop runs on the main context."""
+        if getattr(self, "_inverter", None) is None:
+            from .distributed import arena_tensor
+            from .pipeline import NativeTextEncoder
+            main = self.ldm_stable
+            torch.cuda.synchronize(main.device)
+            self._inv_stream = torch.cuda.Stream(device=main.device)
+            with torch.cuda.device(main.device), torch.cuda.stream(self._inv_stream):
+                native_text = isinstance(main.text_encoder, NativeTextEncoder)
+                p = NativePipeline(main.engine.cfg, device=main.device, max_unet_rows=4, max_vae_images=2, tokenizer=main.tokenizer,
+                                   text_encoder="native" if native_text else main.text_encoder)
+                arena_tensor(p.engine).copy_(arena_tensor(main.engine))
+                self._inv_stream.synchronize()
+                p.engine.mark_all_loaded()
+                p.scheduler.set_timesteps(self.num_ddim_steps)
+            self._inverter = p
+        return self._inverter
+
+    def edit_stream_directinversion(self, items, guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
+                                    is_replace_controller=False):
+        """`directinversion+p2p` over a sequence of images with stage overlap: while image i runs its 50 twelve-row lock-step steps on
+        the main context, image i+1's prompt embedding, VAE encode and 50 ONE-row inversion steps (launches that fill a fraction of the
+        chip) run on a second context / HIP stream from a worker thread.  Same kernels on the same inputs as `edit_image_directinversion`
+        -> identical panels (tests/test_gpu_loops.py); only sweep throughput changes -- the PIE-Bench loop of run_editing_p2p.py:239-300
+        visits images one by one.  items: iterable of (image_path | array, prompt_src, prompt_tar, blend_word, eq_params).  Generator of panels."""
+        from concurrent.futures import ThreadPoolExecutor
+        if self.schedule not in ("faithful", "pruned"):
+            raise ValueError("P2PEditor.schedule must be 'faithful' or 'pruned'")
+        items = list(items)
+        main = self.ldm_stable
+        inverter = self._second_pipeline()
+
+        def stage1(it):
+            with torch.no_grad(), torch.cuda.device(main.device), torch.cuda.stream(self._inv_stream):
+                image_gt, side = self._load(it[0])
+                inv = DirectInversion(model=inverter, num_ddim_steps=self.num_ddim_steps)
+                x = torch.stack(list(self._invert_stage(inverter, inv, image_gt, [it[1], it[2]])))
+                ctx = inv.context.clone()
+                self._inv_stream.synchronize()          # the consumer is another stream: hand over finished tensors
+            return image_gt, side, x, ctx
+
+        with ThreadPoolExecutor(max_workers=1) as ex, torch.no_grad():
+            fut = ex.submit(stage1, items[0]) if items else None
+            for i, it in enumerate(items):
+                image_gt, side, x, ctx = fut.result()
+                for t in (x, ctx):
+                    if t.is_cuda:                        # produced on the worker's stream, consumed on this one
+                        t.record_stream(torch.cuda.current_stream(main.device))
+                if i + 1 < len(items):
+                    fut = ex.submit(stage1, items[i + 1])
+                yield self._edit_stage(x, ctx, image_gt, [it[1], it[2]], it[1], it[2], guidance_scale, cross_replace_steps, self_replace_steps,
+                                       it[3] if len(it) > 3 else None, it[4] if len(it) > 4 else None, is_replace_controller, False, False, side)
 
     @torch.no_grad()
     def edit_images_directinversion(self, image_paths, prompts_src, prompts_tar, guidance_scale=7.5, cross_replace_steps=0.4,

@@ -265,6 +265,32 @@ def test_batched_images_match_single_image_calls():
     pipe.engine.close()
 
 
+@pytest.mark.gpu
+def test_stream_editing_overlaps_stages_and_matches_single_image_calls():
+    """P2PEditor.edit_stream_directinversion: image i+1's embedding / VAE encode / inversion on a second library context and HIP stream
+    (worker thread) under image i's lock-step loop.  Same kernels on the same inputs: the panels equal the one-by-one calls bit for bit,
+    for the faithful and the pruned schedule."""
+    cfg = SMALL64
+    pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=3, pipeline=pipe)
+    from PIL import Image
+    img0 = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    items = [(img0, "a cat sitting on a wooden chair", "a dog sitting on a wooden chair", (("cat",), ("dog",)), {"words": ("dog",), "values": (2,)}),
+             (np.ascontiguousarray(img0[:, ::-1]), "a photograph of a mountain", "a watercolor photograph of a snowy mountain", None, None),
+             (np.ascontiguousarray(img0[::-1]), "a cat sitting on a wooden chair", "a cat sitting on a red chair", None, None)]
+    for schedule in ("faithful", "pruned"):
+        ed.schedule = schedule
+        got = list(ed.edit_stream_directinversion(items))
+        assert len(got) == 3 and got[0].size == (2048, 512)
+        for it, panel in zip(items, got):
+            ref = ed.edit_image_directinversion(it[0], it[1], it[2], blend_word=it[3], eq_params=it[4])
+            assert np.array_equal(np.array(panel), np.array(ref)), schedule
+    assert list(ed.edit_stream_directinversion([])) == []
+    ed._inverter.engine.close()
+    pipe.engine.close()
+
+
 VARIANTS = ["ddim+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5", "ablation_directinversion_04+p2p",
             "ablation_directinversion_interval_2+p2p", "ablation_directinversion_add-target+p2p"]
 
