@@ -48,6 +48,8 @@ def main(argv=None):
     ap.add_argument("--edit_category_list", nargs="+", type=str, default=[str(i) for i in range(10)])
     ap.add_argument("--edit_method_list", nargs="+", type=str, default=["directinversion+p2p"])
     ap.add_argument("--batch_size", type=int, default=1, help="images per set of launches and GPU (not in the reference: it edits one by one)")
+    ap.add_argument("--overlap_stages", action="store_true",
+                    help="directinversion+p2p, batch_size 1: invert the next image on a second HIP stream while this one is edited (same panels)")
     ap.add_argument("--model_config", choices=("sd1", "small64"), default="sd1", help="small64: reduced-width test configuration")
     ap.add_argument("--num_ddim_steps", type=int, default=50)
     add_weight_args(ap)
@@ -98,6 +100,17 @@ def main(argv=None):
                 continue
             todo.append((src, tgt, image_path, blended, out_path))
         nb = args.batch_size if method in BATCHED_METHODS else 1
+        if args.overlap_stages and nb == 1 and method == "directinversion+p2p":
+            setup_seed()
+            stream_items = [(c[2], c[0], c[1], ((c[3][0],), (c[3][1],)) if c[3] else None,
+                             {"words": (c[3][1],), "values": (2,)} if c[3] else None) for c in todo]
+            for c, panel in zip(todo, editor.edit_stream_directinversion(stream_items, guidance_scale=7.5, cross_replace_steps=0.4,
+                                                                         self_replace_steps=0.6)):
+                print(f"editing image [{c[2]}] with [{method}]")
+                os.makedirs(os.path.dirname(c[4]), exist_ok=True)
+                panel.save(c[4])
+                print("finish")
+            continue
         for b0 in range(0, len(todo), nb):
             chunk = todo[b0:b0 + nb]
             for (_, _, image_path, _, _) in chunk:
