@@ -3,6 +3,7 @@
 // torch.nn.LayerNorm (attention.py:186-188), GEGLU (attention.py:323-333), softmax (attention.py:77),
 // TimestepEmbedding / time_emb_proj linears (embeddings.py:63-80, resnet.py:292,349).
 // All statistics are fp32; 16-byte (8 x fp16) vector accesses, NHWC so that a wavefront reads contiguous channels.
+#include <algorithm>
 #include "ops.h"
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict_
 // Small feature maps (16x16 / 8x8 levels): one block per (batch item, group) does everything in ONE launch -- the group's
 // HW x cpg slice is parked in LDS between the statistics pass and the apply pass.  These tensors are < 1 MB; three dependent
 // launches were pure latency.
+static constexpr int GN_SMALL_ELEMS = 24576;   // largest (sample, group) slice of gn_small_kernel: its registers hold the slice
 template <int NT>
 __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1, int C2,
                                                        int HW, int G, float eps, const float* __restrict__ gamma,
@@ -169,15 +171,47 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__
   const int C = C1 + C2, cpg = C / G, v4 = cpg >> 2;
   const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const int nvec = HW * v4;
+  floatx4* s_ga = reinterpret_cast<floatx4*>(smem_raw + (((size_t)nvec * sizeof(half4) + 15) & ~(size_t)15));   // the group's gamma, then beta
+  floatx4* s_be = s_ga + v4;
+  constexpr int GPT = 1024 / NT;               // cpg <= 1024: affine parameters per thread, loaded (clamped) ahead of the data loads
+  float ga_r[GPT], be_r[GPT];
+#pragma unroll
+  for (int u = 0; u < GPT; ++u) {
+    const int cl = min(tid + u * NT, cpg - 1);
+    ga_r[u] = gamma[g * cpg + cl];
+    be_r[u] = beta[g * cpg + cl];
+  }
   float s = 0.f, q = 0.f;
-  for (int idx = tid; idx < nvec; idx += NT) {
+  // Every slice of the thread in flight at once: MAXV clamped (unpredicated) 8-byte loads issued back to back in straight-line code,
+  // then consumed in index order -- the one-load-one-wait loop this replaces was a chain of up to six HBM / L2 round trips per
+  // thread in a kernel that is pure latency (a loop around batches makes the compiler drain the counter at the loop header).
+  constexpr int MAXV = GN_SMALL_ELEMS / 4 / NT;
+  half4 val[MAXV];
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const int idx = min(tid + u * NT, nvec - 1);
     const int pix = idx / v4, v = idx - pix * v4;
     const int c = g * cpg + 4 * v;
-    const half_t* src = c < C1 ? x1 + ((size_t)b * HW + pix) * C1 + c : x2 + ((size_t)b * HW + pix) * C2 + (c - C1);
-    const half4 val = *reinterpret_cast<const half4*>(src);
-    s_x[idx] = val;
+    const bool first = c < C1;            // selects on the operands, one address computation: no divergent control flow between the loads
+    const half_t* sb = first ? x1 : x2;
+    const int ld = first ? C1 : C2, cc = first ? c : c - C1;
+    val[u] = *reinterpret_cast<const half4*>(sb + ((size_t)b * HW + pix) * ld + cc);
+  }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { float f = (float)val[j]; s += f; q += f * f; }
+  for (int u = 0; u < MAXV; ++u) {
+    const int idx = tid + u * NT;
+    const bool ok = idx < nvec;
+    if (ok) s_x[idx] = val[u];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // unconditional use (a clamped duplicate adds exact zeros): keeps every load ahead of the first wait
+      const float f = ok ? (float)val[u][j] : 0.f;
+      s += f; q += f * f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < GPT; ++u) {              // read back as one float4 per 4-channel vector
+    const int cl = tid + u * NT;
+    if (cl < cpg) { reinterpret_cast<float*>(s_ga)[cl] = ga_r[u]; reinterpret_cast<float*>(s_be)[cl] = be_r[u]; }
   }
   s = wave_sum(s); q = wave_sum(q);
   if ((tid & 63) == 0) { s_s[tid >> 6] = s; s_q[tid >> 6] = q; }
@@ -194,11 +228,12 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__
     const int pix = idx / v4, v = idx - pix * v4;
     const int c = g * cpg + 4 * v;
     const half4 val = s_x[idx];
+    const floatx4 ga = s_ga[v], be = s_be[v];
     half4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float sc = rstd * gamma[c + j];
-      float f = ((float)val[j] - mean) * sc + beta[c + j];
+      const float sc = rstd * ga[j];
+      float f = ((float)val[j] - mean) * sc + be[j];
       if (silu) f = silu_f(f);
       o[j] = (half_t)f;
     }
@@ -206,29 +241,29 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__
   }
 }
 
-static int gn_small_max() {
-  static const int v = getenv("PNPI_GN_SMALL_MAX") ? atoi(getenv("PNPI_GN_SMALL_MAX")) : 24576;
+static int gn_small_max() {     // elements per (sample, group) slice handled by the one-launch kernel (PNPI_GN_SMALL_MAX lowers it)
+  static const int v = getenv("PNPI_GN_SMALL_MAX") ? std::min(atoi(getenv("PNPI_GN_SMALL_MAX")), GN_SMALL_ELEMS) : GN_SMALL_ELEMS;
   return v;
 }
 static bool gn_small_ok(int C1, int C2, int HW, int G) {
   const int C = C1 + C2, cpg = C / G;
-  return (cpg % 4 == 0) && (C1 % 4 == 0) && ((size_t)HW * cpg <= (size_t)gn_small_max());
+  return (cpg % 4 == 0) && (C1 % 4 == 0) && cpg <= 1024 && ((size_t)HW * cpg <= (size_t)gn_small_max());   // gamma / beta: 8 KB of LDS at most
 }
 static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                            const float* beta, int silu, half_t* out, hipStream_t st) {
   const int cpg = (C1 + C2) / G;
   static unsigned long long attr_devs = 0;
   if (first_on_device(attr_devs)) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2));
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2 + 8192));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2 + 8192));
   }
   // 1024-thread blocks: each (sample, group) slice is a latency chain load -> reduce -> normalise -> store, and four times
   // the lanes per slice shorten it at every row count measured (1 row: 16.2 -> 12.7 us per launch; 12 rows: 23.0 -> 20.7)
   static const int wide_below = getenv("PNPI_GN_WIDE_BELOW") ? atoi(getenv("PNPI_GN_WIDE_BELOW")) : (1 << 30);
   if (B * G < wide_below)
-    gn_small_kernel<1024><<<dim3(B, G), 1024, (size_t)HW * cpg * sizeof(half_t), st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
+    gn_small_kernel<1024><<<dim3(B, G), 1024, (size_t)HW * cpg * sizeof(half_t) + (size_t)cpg * 8 + 16, st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
   else
-    gn_small_kernel<256><<<dim3(B, G), 256, (size_t)HW * cpg * sizeof(half_t), st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
+    gn_small_kernel<256><<<dim3(B, G), 256, (size_t)HW * cpg * sizeof(half_t) + (size_t)cpg * 8 + 16, st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
   return (int)hipGetLastError();
 }
 

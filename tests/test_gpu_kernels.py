@@ -237,7 +237,11 @@ def test_conv1x1_concat(ctx):
 
 # ------------------------------------------------------------------------------------------------ norms / elementwise
 @pytest.mark.parametrize("B,C1,C2,HW,silu,eps", [(2, 320, 0, 256, 1, 1e-5), (2, 64, 32, 64, 1, 1e-6), (3, 32, 0, 16, 0, 1e-6),
-                                                 (1, 1280, 1280, 64, 1, 1e-5), (1, 128, 0, 4096, 1, 1e-6)])
+                                                 (1, 1280, 1280, 64, 1, 1e-5), (1, 128, 0, 4096, 1, 1e-6),
+                                                 # the one-launch kernel (HW * C / 32 <= 24576): 5 of its 6 register slices, a group that
+                                                 # straddles the two concat sources, the largest slice, a 2 x 2 map
+                                                 (2, 640, 0, 1024, 1, 1e-5), (1, 1280, 640, 256, 1, 1e-5), (3, 768, 0, 1024, 0, 1e-6),
+                                                 (2, 1280, 0, 4, 1, 1e-5), (12, 2560, 0, 64, 1, 1e-5)])
 def test_groupnorm(ctx, B, C1, C2, HW, silu, eps):
     C = C1 + C2
     x1 = (h16(B, HW, C1, seed=13).float() * 2 + 0.5).half()
