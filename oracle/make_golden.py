@@ -18,6 +18,8 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
   e2e_proximal.npz     P2PEditor("negative-prompt-inversion+proximal-guidance") with the sweep script's arguments (l0) and l1
   e2e_proximal_recon.npz  the same method with use_reconstruction_guidance=True (masked pred-x0 pull + dilated edit mask), 4 steps
+  e2e_null_text.npz    P2PEditor("null-text-inversion+p2p"): inversion latents, the optimised per-step unconditional embeddings, the loss
+                       of every Adam iteration, reconstruction / edited latents (pins the oracle of the not-yet-built native path)
   clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
   method_dispatch.json P2PEditor.__call__'s routing of its 39 method strings (handler + method-specific arguments)
 """
@@ -378,6 +380,59 @@ def proximal_recon(steps=4):
     np.savez_compressed(os.path.join(OUT, "e2e_proximal_recon.npz"), **out)
 
 
+def null_text(steps=3):
+    """P2PEditor("null-text-inversion+p2p") of the reference (models/p2p_editor.py:199-259): NullInversion.invert = ddim_inversion +
+    null_optimization (10 Adam iterations per step through the UNet w.r.t. the 77 x D unconditional embedding, inversion.py:196-234),
+    then p2p_guidance_forward twice with the per-step embeddings.  Same image / prompts / weights / controller as e2e_refine.
+    The native path does not build this method yet (it needs the UNet backward pass); the fixture pins the ORACLE's restatement
+    (oracle/p2p_oracle.py: null_optimization) so that the device implementation has a checker waiting."""
+    ref_shim.install()
+    cfg = SMALL64
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, w0, w1 = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    import models.p2p_editor as pe
+    import models.p2p.inversion as inv
+    t0 = time.time()
+    calls, stages, losses = [], {}, []
+    orig_fwd, orig_inv = pe.p2p_guidance_forward, inv.NullInversion.invert
+    orig_mse = inv.nnf.mse_loss
+
+    def spy_fwd(*a, **k):
+        r = orig_fwd(*a, **k)
+        calls.append(r[0].clone().numpy())
+        return r
+
+    def spy_inv(self, *a, **k):
+        r = orig_inv(self, *a, **k)
+        stages["x_stars"] = torch.stack([x.clone() for x in r[2]]).numpy()
+        stages["uncond"] = torch.stack([x.clone() for x in r[3]]).numpy()
+        stages["context"] = self.context.clone().numpy()
+        return r
+
+    def spy_mse(*a, **k):
+        r = orig_mse(*a, **k)
+        losses.append(float(r.detach()))
+        return r
+
+    pe.p2p_guidance_forward, inv.NullInversion.invert, inv.nnf.mse_loss = spy_fwd, spy_inv, spy_mse
+    try:
+        with ref_shim.cuda_to_cpu():           # NOT under no_grad: null_optimization differentiates through the UNet
+            panel = ed("null-text-inversion+p2p", image_path=img, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5, cross_replace_steps=0.4,
+                       self_replace_steps=0.6, blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)},
+                       is_replace_controller=False)
+    finally:
+        pe.p2p_guidance_forward, inv.NullInversion.invert, inv.nnf.mse_loss = orig_fwd, orig_inv, orig_mse
+    assert len(calls) == 2
+    np.savez_compressed(os.path.join(OUT, "e2e_null_text.npz"), x_stars=stages["x_stars"], uncond_embeddings=stages["uncond"],
+                        context=stages["context"], losses=np.array(losses, dtype=np.float64), reconstruct_latent=calls[0],
+                        edited_latents=calls[1], edited_image_small=np.array(panel)[::4, 3 * 512::4], steps=np.int64(steps), src=src, tgt=tgt,
+                        blend=np.array([w0, w1]))
+    print("null_text %.1fs, %d inner iterations, loss %.3e -> %.3e" % (time.time() - t0, len(losses), losses[0], losses[-1]))
+
+
 def masactrl(steps=6, start_step=2, start_layer=10):
     """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -469,6 +524,8 @@ if __name__ == "__main__":
         proximal()
     if "proximal_recon" in which or not sys.argv[1:]:
         proximal_recon()
+    if "null_text" in which or not sys.argv[1:]:
+        null_text()
     if "clip" in which:
         clip_text()
     if "dispatch" in which:

@@ -2,6 +2,7 @@
 the three DI lines, the attention controllers and LocalBlend, restated in plain PyTorch/numpy from
 
   models/p2p/inversion.py:245-400          (DirectInversion: next_step, prev_step, ddim_loop, offset_calculate)
+  models/p2p/inversion.py:196-234          (NullInversion.null_optimization / invert: the oracle of the not-yet-built null-text path)
   models/p2p/p2p_guidance_forward.py:103-173 (direct_inversion_p2p_guidance_{diffusion_step,forward})
   models/p2p/scheduler_dev.py:38-95        (DDIMSchedulerDev.step, eta = 0)
   models/p2p/attention_control.py:95-363   (LocalBlend, AttentionStore, AttentionControlEdit, Replace/Refine/Reweight)
@@ -263,18 +264,27 @@ def offset_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guid
 
 
 def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timesteps, ac, final, guidance_scale, offset_rows=1,
-                     collect=None, prox=None, quantile=0.7, recon=None):
+                     collect=None, prox=None, quantile=0.7, recon=None, uncond_list=None, uncond_first_only=False):
     """direct_inversion_p2p_guidance_forward (p2p_guidance_forward.py:135-173) + ..._diffusion_step (:103-116).
     prox 'l0' / 'l1': the proximal step of proximal_guidance_diffusion_step (proximal_guidance_forward.py:39-64), no inversion
     guidance (what the reference's editors reach).  recon = dict(ref_image, recon_lr, recon_t, dilate_mask): reconstruction
-    guidance (:48-51,60-72 + DDIMSchedulerDev.step's ref_image / recon_mask branch, scheduler_dev.py:68-76)."""
+    guidance (:48-51,60-72 + DDIMSchedulerDev.step's ref_image / recon_mask branch, scheduler_dev.py:68-76).
+    uncond_list: per-step [1, 77, D] unconditional embeddings (null-text inversion).  p2p_guidance_forward (p2p_guidance_forward.py:
+    21-62) uses the step's embedding for EVERY unconditional row (`uncond_embeddings[i].expand(*text_embeddings.shape)`);
+    uncond_first_only = the single-branch variant (:65-100: `cat([uncond_embeddings[i], uncond_embeddings_[1:]])`)."""
     n = len(timesteps)
     ratio = len(ac) // n
     nrow = context4.shape[0] // 2
     lat = x_T.expand(nrow, *x_T.shape[1:]).clone()
     for i in range(n):
         t = int(timesteps[i])
-        eps = unet_fn(torch.cat([lat] * 2), t, context4, controller)
+        if uncond_list is None:
+            ctx_i = context4
+        elif uncond_first_only:
+            ctx_i = torch.cat([uncond_list[i], context4[1:]])
+        else:
+            ctx_i = torch.cat([uncond_list[i].expand(nrow, *uncond_list[i].shape[1:]), context4[nrow:]])
+        eps = unet_fn(torch.cat([lat] * 2), t, ctx_i, controller)
         eu, ec = eps.chunk(2)
         d = ec - eu
         if prox is not None:
@@ -305,6 +315,57 @@ def guidance_forward(unet_fn, x_T, context4, noise_loss_list, controller, timest
         if collect is not None:
             collect.append(lat.clone())
     return lat
+
+
+def null_optimization(unet_fn, ddim_latents, ctx_uncond, ctx_cond, timesteps, ac, final, guidance_scale, num_inner_steps=10,
+                      epsilon=1e-5, trace=None, total_steps=None):
+    """NullInversion.null_optimization (inversion.py:196-225): per DDIM step (t descending) up to `num_inner_steps` Adam iterations on
+    the 77 x D unconditional embedding so that one CFG prev_step from latent_cur lands on the stored inversion latent; then the step
+    is taken with the optimised embedding.  unet_fn must be differentiable w.r.t. its context argument (the oracle's UNet is plain
+    torch).  Adam is written out (torch.optim.Adam defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay; a NEW optimiser per
+    DDIM step, lr = 1e-2 (1 - i / 100)) so that a device implementation has the formula to match.  Returns the list of [1, 77, D]
+    embeddings; trace (a list) receives (step, inner iterations run, last loss).  total_steps: the schedule length when `timesteps` is
+    only its first part (tests)."""
+    n = len(timesteps)
+    ratio = len(ac) // (total_steps or n)
+    uncond = ctx_uncond.clone()
+    out = []
+    latent_cur = ddim_latents[-1]
+    for i in range(n):
+        uncond = uncond.clone().detach()
+        t = int(timesteps[i])
+        a_t, a_p = prev_alphas(ac, final, t, ratio)
+        its, loss_item = 0, None
+        if num_inner_steps != 0:
+            lr = 1e-2 * (1.0 - i / 100.0)
+            m, v = torch.zeros_like(uncond), torch.zeros_like(uncond)
+            latent_prev = ddim_latents[len(ddim_latents) - i - 2]
+            with torch.no_grad():
+                eps_cond = unet_fn(latent_cur, t, ctx_cond, None)
+            for j in range(num_inner_steps):
+                u = uncond.clone().detach().requires_grad_(True)
+                with torch.enable_grad():
+                    eps_unc = unet_fn(latent_cur, t, u, None)
+                    eps = eps_unc + guidance_scale * (eps_cond - eps_unc)
+                    rec = ddim_move(latent_cur, eps, float(a_t), float(a_p))
+                    loss = F.mse_loss(rec, latent_prev)
+                g, = torch.autograd.grad(loss, u)
+                k = j + 1
+                m = 0.9 * m + 0.1 * g
+                v = 0.999 * v + 0.001 * g * g
+                denom = (v.sqrt() / (1 - 0.999 ** k) ** 0.5) + 1e-8
+                uncond = (uncond - (lr / (1 - 0.9 ** k)) * (m / denom)).detach()
+                its, loss_item = k, float(loss.detach())
+                if loss_item < epsilon + i * 2e-5:
+                    break
+        if trace is not None:
+            trace.append((i, its, loss_item))
+        out.append(uncond[:1].detach())
+        with torch.no_grad():
+            eu = unet_fn(latent_cur, t, uncond, None)
+            ec = unet_fn(latent_cur, t, ctx_cond, None)
+            latent_cur = ddim_move(latent_cur, eu + guidance_scale * (ec - eu), float(a_t), float(a_p))
+    return out
 
 
 def image2latent(vae_encode_mean_fn, image_u8):
