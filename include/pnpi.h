@@ -258,8 +258,13 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
                        int ksize, int stride, int pad, int upsample, int Ho, int Wo, const void* w_f16, const float* bias,
                        const void* residual_f16, int N, void* out_nhwc_f16, int force_cfg, int force_split, float* stats_out,
                        int* tile_rows_out);
-/* process-wide kernel tuning knobs ("igemm_v320", "igemm_v256n", "igemm_v128", "igemm_v64", "igemm_wide", "igemm_dma",
- * "tile_order", ...): variant A/B inside one process and tests of non-default variants; PNPI_EINVAL for an unknown key */
+/* process-wide kernel tuning knobs: variant A/B inside one process (tools/fwd_ab.py, tools/fwd_tune.py) and tests of non-default
+ * variants; PNPI_EINVAL for an unknown key.  Keys (default): "text_kv" (1) / "temb_cache" (1) per-loop caches; "gn_inline_rows" (0)
+ * one-launch GroupNorm below this many rows; "igemm_dma" (1) LDS-DMA kernel family; "igemm_table" (1) measured tile table before the
+ * cost model; "igemm_wide" (1) 128x320 / 128x256 tiles; "igemm_deep_rings" (1) deeper LDS rings on sparse launches; "igemm_vt_lds" (1)
+ * transposed V^T epilogue through LDS; "igemm_bias_init" (1) bias as the accumulators' initial value; "igemm_res_late" (0) residual
+ * added in the store loop; "igemm_force_cfg" (-1) / "igemm_force_split" (0) one tile id / split-K for every launch (sweeps);
+ * "igemm_v128", "igemm_v64", "igemm_v256", "igemm_v320", "igemm_v256n" variant of a tile id; "tile_order" (-1) XCD traversal order. */
 int pnpi_set_tuning(const char* key, int value);
 int pnpi_op_gemm(pnpi_ctx* ctx, const void* a_f16, int lda, const void* w_f16, int ldw, int M, int N, int K, float alpha,
                  const float* bias, const void* residual_f16, void* out_f16, int ldo, int vt_col0, void* outT,
