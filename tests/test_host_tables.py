@@ -149,3 +149,52 @@ def test_clip_bpe_tokenizer_matches_transformers():
             assert ref.decode([tok]) == mine.decode([tok]), (tok, ref.decode([tok]), mine.decode([tok]))
     # the reference's word-index helper works on it (utils/utils.py:84-102)
     assert get_word_inds("a cat sitting on the wooden chair", "cat", mine).tolist() == get_word_inds("a cat sitting on the wooden chair", "cat", ref).tolist() == [2]
+
+
+def test_random_prompt_pairs_against_the_live_reference():
+    """Where /root/reference is present (the build container; the GPU box has only the committed goldens above): 60 seeded random
+    prompt pairs -- substitutions, insertions, deletions, repeated words, different lengths -- through the reference's own
+    seq_aligner / get_time_words_attention_alpha / get_equalizer / LocalBlend and through the product's, bit for bit."""
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree not on this machine")
+    ref_shim.install()
+    from models.p2p import seq_aligner as ref_sa
+    from models.p2p.attention_control import LocalBlend as RefLB, get_equalizer as ref_eq
+    from utils.utils import get_time_words_attention_alpha as ref_alpha, get_word_inds as ref_inds
+    import torch
+    tok = WordTokenizer()
+    vocab = "a the cat dog sitting on wooden red chair photo of mountain snowy watercolor big small tree and with elephant walking".split()
+    rng = np.random.default_rng(1234)
+    n_replace = 0
+    for case in range(60):
+        src = [vocab[i] for i in rng.integers(0, len(vocab), rng.integers(3, 12))]
+        tgt = list(src)
+        for _ in range(rng.integers(1, 4)):                      # 1-3 edits
+            op, pos = rng.integers(0, 3), int(rng.integers(0, len(tgt)))
+            w = vocab[int(rng.integers(0, len(vocab)))]
+            if op == 0:
+                tgt[pos] = w
+            elif op == 1:
+                tgt.insert(pos, w)
+            elif len(tgt) > 2:
+                del tgt[pos]
+        ps, pt = " ".join(src), " ".join(tgt)
+        m, a = seq_aligner.get_refinement_mapper([ps, pt], tok)
+        rm, ra = ref_sa.get_refinement_mapper([ps, pt], tok)
+        assert torch.equal(torch.as_tensor(m), rm) and torch.equal(torch.as_tensor(a), ra), (ps, pt)
+        if len(src) == len(tgt):
+            n_replace += 1
+            assert torch.equal(torch.as_tensor(seq_aligner.get_replacement_mapper([ps, pt], tok)), ref_sa.get_replacement_mapper([ps, pt], tok)), (ps, pt)
+        w0, w1 = src[int(rng.integers(0, len(src)))], tgt[int(rng.integers(0, len(tgt)))]
+        assert get_word_inds(ps, w0, tok).tolist() == ref_inds(ps, w0, tok).tolist()
+        for steps, frac in ((50, 0.4), (7, {"default_": 0.8, w1: (0.1, 0.5)})):
+            cr = frac if isinstance(frac, dict) else {"default_": frac}
+            got = get_time_words_attention_alpha([ps, pt], steps, cr, tok)
+            assert torch.equal(torch.as_tensor(got), ref_alpha([ps, pt], steps, dict(cr), tok)), (ps, pt, steps)
+        assert torch.equal(torch.as_tensor(ac.get_equalizer(pt, (w1,), (2.5,), tokenizer=tok)), ref_eq(pt, (w1,), (2.5,), tokenizer=tok))
+        with ref_shim.cuda_to_cpu():
+            rlb = RefLB([ps, pt], ((w0,), (w1,)), tokenizer=tok, num_ddim_steps=50)
+        lb = ac.LocalBlend([ps, pt], ((w0,), (w1,)), tokenizer=tok, num_ddim_steps=50)
+        assert torch.equal(torch.as_tensor(lb.alpha_layers).reshape(-1), rlb.alpha_layers.reshape(-1).cpu()) and lb.start_blend == rlb.start_blend
+    assert n_replace >= 5
