@@ -169,7 +169,8 @@ int pnpi_set_attention_callback(pnpi_ctx* ctx, pnpi_attn_callback cb, void* user
 /* Cross-attention keys / values of the 16 transformer blocks for `rows` context rows (device fp32 [rows][77][768]); they depend on
  * the text only (CrossAttention.to_k / to_v on encoder_hidden_states, my_diffusers/models/attention.py:230-234, evaluated by the
  * reference inside every one of its 650 UNet calls per image).  pnpi_unet_forward(..., context = NULL, ...) then reads the cache
- * (rows must match); the level-2 loops below precompute it themselves once per loop. */
+ * (rows must match); the level-2 loops below precompute it themselves once per loop and drop it at their end (a loop call
+ * therefore also invalidates a cache filled here). */
 int pnpi_text_kv_precompute(pnpi_ctx* ctx, const float* context, int rows);
 /* controller.step_callback -> LocalBlend.__call__ (attention_control.py:108-121,253-256) for level-1 drivers:
  * latents [nimg][2][4][h][w] updated in place, using the maps accumulated by the preceding pnpi_unet_forward calls */

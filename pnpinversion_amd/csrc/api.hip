@@ -1463,15 +1463,19 @@ int pnpi_text_encode(pnpi_ctx* c, const int32_t* input_ids, int n, float* hidden
 // The loops' text context is constant over their steps: project K / V once, then every forward of the loop reads the cache.
 struct LoopKV {
   pnpi_ctx* c;
+  bool armed = false;
   explicit LoopKV(pnpi_ctx* c_) : c(c_) {}
   int begin(const float* context, int rows) {
     if (!g_text_kv) return 0;
     int r = text_kv_precompute(c, context, rows);
     if (r) return r;
     c->tkv.use = true;
+    armed = true;
     return 0;
   }
-  ~LoopKV() { c->tkv.use = false; }
+  // a loop's projections belong to the loop's context: dropped at its end, so that a later pnpi_unet_forward(context = NULL) can
+  // never silently read them (it fails and names pnpi_text_kv_precompute instead)
+  ~LoopKV() { if (armed) { c->tkv.use = false; c->tkv.rows = 0; } }
 };
 int pnpi_ddim_invert(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_cond, int nsteps, const int* ts, float* all) {
   if (!c || !z0 || !ctx_cond || !ts || !all || nsteps <= 0) return PNPI_EINVAL;
