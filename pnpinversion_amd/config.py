@@ -3,7 +3,7 @@
 SD-1.x values: diffusers ctor args of UNet2DConditionModel / AutoencoderKL as used by the reference
 (models/edict/my_diffusers/models/unet_2d_condition.py:57-82, vae.py:508-519) and the in-tree v1-inference.yaml
 (models/instructpix2pix/stable_diffusion/configs/stable-diffusion/v1-inference.yaml:29-65)."""
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Tuple
 
 

@@ -6,7 +6,6 @@ torch.distributed.run the work list is sharded over the ranks exactly like run_e
 import argparse
 import json
 import os
-import random
 
 import numpy as np
 import torch

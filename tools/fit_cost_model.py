@@ -1,6 +1,6 @@
 """Offline refit of launch_igemm's tile / split-K cost model against tools/autotune_report.py tables (gpurun_out/autotune_b*.txt).
 Evaluates the regret (time of the model's pick minus the best measured configuration, weighted by launches per forward)."""
-import glob, itertools, math, re, sys
+import glob, itertools, re
 
 def parse(fn):
     recs = []
