@@ -324,7 +324,7 @@ def null_optimization(unet_fn, ddim_latents, ctx_uncond, ctx_cond, timesteps, ac
     is taken with the optimised embedding.  unet_fn must be differentiable w.r.t. its context argument (the oracle's UNet is plain
     torch).  Adam is written out (torch.optim.Adam defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay; a NEW optimiser per
     DDIM step, lr = 1e-2 (1 - i / 100)) so that a device implementation has the formula to match.  Returns the list of [1, 77, D]
-    embeddings; trace (a list) receives (step, inner iterations run, last loss).  total_steps: the schedule length when `timesteps` is
+    embeddings; trace (a list) receives (step, inner iterations run, last loss, [every iteration's loss]).  total_steps: the schedule length when `timesteps` is
     only its first part (tests)."""
     n = len(timesteps)
     ratio = len(ac) // (total_steps or n)
@@ -335,7 +335,7 @@ def null_optimization(unet_fn, ddim_latents, ctx_uncond, ctx_cond, timesteps, ac
         uncond = uncond.clone().detach()
         t = int(timesteps[i])
         a_t, a_p = prev_alphas(ac, final, t, ratio)
-        its, loss_item = 0, None
+        its, loss_item, all_losses = 0, None, []
         if num_inner_steps != 0:
             lr = 1e-2 * (1.0 - i / 100.0)
             m, v = torch.zeros_like(uncond), torch.zeros_like(uncond)
@@ -356,10 +356,11 @@ def null_optimization(unet_fn, ddim_latents, ctx_uncond, ctx_cond, timesteps, ac
                 denom = (v.sqrt() / (1 - 0.999 ** k) ** 0.5) + 1e-8
                 uncond = (uncond - (lr / (1 - 0.9 ** k)) * (m / denom)).detach()
                 its, loss_item = k, float(loss.detach())
+                all_losses.append(loss_item)
                 if loss_item < epsilon + i * 2e-5:
                     break
         if trace is not None:
-            trace.append((i, its, loss_item))
+            trace.append((i, its, loss_item, all_losses))
         out.append(uncond[:1].detach())
         with torch.no_grad():
             eu = unet_fn(latent_cur, t, uncond, None)

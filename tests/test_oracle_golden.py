@@ -16,6 +16,8 @@ from pnpinversion_amd.config import SD1, SMALL64, TINY16
 from pnpinversion_amd.p2p import attention_control as ac
 from pnpinversion_amd.text import SyntheticTextEncoder, WordTokenizer
 
+SLOW = os.environ.get("PNPI_SLOW_TESTS", "0") == "1"     # the CPU suite is bounded: a few checks that only repeat a pinned path run on request
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -254,9 +256,10 @@ def test_reconstruction_guidance_matches_reference():
         flipped = (out - want).abs() > 1e-2
         assert int(flipped.sum()) <= 16, (prox, int(flipped.sum()))
         assert rel(out[~flipped], want[~flipped]) < 5e-5, (prox, rel(out[~flipped], want[~flipped]))
-    plain = po.guidance_forward(unet_fn, x_stars[-1], c4, None, po.EditController(32, _tables_from_product(g, steps)), ts, ac_, ac_[0], 7.5,
-                                prox="l0", quantile=0.75)
-    assert rel(plain, v["l0/edited_latents"]) > 1e-3                # the pull matters
+    if SLOW:    # one more 4-step pass: without the pull the result is measurably different (1.3e-1 when the fixture was made)
+        plain = po.guidance_forward(unet_fn, x_stars[-1], c4, None, po.EditController(32, _tables_from_product(g, steps)), ts, ac_, ac_[0], 7.5,
+                                    prox="l0", quantile=0.75)
+        assert rel(plain, v["l0/edited_latents"]) > 1e-3
 
 
 @pytest.mark.parametrize("name,cfg", [("tiny", TINY16), ("sd1", SD1)])
@@ -273,8 +276,8 @@ def test_null_text_optimization_matches_reference():
     """NullInversion.invert + the two p2p_guidance_forward calls of P2PEditor("null-text-inversion+p2p") (inversion.py:196-234,
     p2p_editor.py:199-259) against the oracle's restatement (p2p_oracle.null_optimization: autograd through the oracle UNet w.r.t. the
     77 x D unconditional embedding, Adam written out).  The native path does not build this method yet; this pins its checker.
-    Only the first of the three DDIM steps is optimised here (10 of the 30 Adam iterations, then the CFG step with the optimised
-    embedding is implied by the next step's inputs) to bound the CPU suite; `python -m oracle.make_golden null_text` regenerates it."""
+    Only the first of the three DDIM steps is optimised here, 3 of its 10 Adam iterations by default (PNPI_SLOW_TESTS=1: all 10 and the
+    resulting embedding), to bound the CPU suite."""
     g = load("e2e_null_text.npz")
     cfg, steps = SMALL64, int(g["steps"])
     usd = weights.unet_state_dict(cfg, 2)
@@ -289,14 +292,16 @@ def test_null_text_optimization_matches_reference():
         lat = po.ddim_loop(unet_fn, x_stars[0], ctx2[1:], ts, ac_, ac_[0])
     assert rel(torch.stack(lat), x_stars) < 2e-5
     trace = []
-    unc = po.null_optimization(unet_fn, [x for x in x_stars], ctx2[:1], ctx2[1:], ts[:1], ac_, ac_[0], 7.5, num_inner_steps=10,
+    n_it = 10 if SLOW else 3                      # every iteration's loss is in the fixture: 3 pin the gradient and two Adam updates
+    unc = po.null_optimization(unet_fn, [x for x in x_stars], ctx2[:1], ctx2[1:], ts[:1], ac_, ac_[0], 7.5, num_inner_steps=n_it,
                                epsilon=1e-5, trace=trace, total_steps=steps)
     ref_unc = torch.from_numpy(g["uncond_embeddings"])
-    assert [t_[1] for t_ in trace] == [10]                           # synthetic weights: no early stop, as in the reference run
-    for i in range(1):
-        assert rel(unc[i], ref_unc[i]) < 2e-4, (i, rel(unc[i], ref_unc[i]))
-        assert rel(unc[i], ctx2[:1]) > 1e-2                          # the embedding did move
-        assert abs(trace[i][2] - g["losses"][10 * i + 9]) < 1e-4 * abs(g["losses"][10 * i + 9])
+    assert trace[0][1] == n_it                                       # synthetic weights: no early stop, as in the reference run
+    for j, loss in enumerate(trace[0][3]):
+        assert abs(loss - g["losses"][j]) < 1e-4 * abs(g["losses"][j]), (j, loss, g["losses"][j])
+    assert rel(unc[0], ctx2[:1]) > 1e-3                              # the embedding did move
+    if SLOW:
+        assert rel(unc[0], ref_unc[0]) < 2e-4, rel(unc[0], ref_unc[0])
     # the guidance passes with the REFERENCE's embeddings (so that this half does not depend on the 30 iterations above)
     from pnpinversion_amd.text import SyntheticTextEncoder
     tok, enc = WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7)
