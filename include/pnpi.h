@@ -265,8 +265,13 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
  * cost model; "igemm_wide" (1) 128x320 / 128x256 tiles; "igemm_deep_rings" (1) deeper LDS rings on sparse launches; "igemm_vt_lds" (1)
  * transposed V^T epilogue through LDS; "igemm_bias_init" (1) bias as the accumulators' initial value; "igemm_res_late" (0) residual
  * added in the store loop; "igemm_force_cfg" (-1) / "igemm_force_split" (0) one tile id / split-K for every launch (sweeps);
- * "igemm_v128", "igemm_v64", "igemm_v256", "igemm_v320", "igemm_v256n" variant of a tile id; "tile_order" (-1) XCD traversal order. */
+ * "igemm_table_near" (1) nearest-row-count table entry for untabled M; "igemm_v128", "igemm_v64", "igemm_v256", "igemm_v320",
+ * "igemm_v256n" variant of a tile id; "tile_order" (-1) XCD traversal order. */
 int pnpi_set_tuning(const char* key, int value);
+/* Host-only query of the measured tile table launch_igemm consults before its cost model (no device work; used by the CPU tests):
+ * returns 1 for an exact {M, N, K, ksize} entry, 2 when the same layer (N, K, ksize) is listed at another row count and the entry
+ * nearest in M (at most 4x away) is used, 0 for none; cfg / split / entry_m (each nullable) receive the entry. */
+int pnpi_tile_table_lookup(int M, int N, int K, int ksize, int* cfg, int* split, int* entry_m);
 int pnpi_op_gemm(pnpi_ctx* ctx, const void* a_f16, int lda, const void* w_f16, int ldw, int M, int N, int K, float alpha,
                  const float* bias, const void* residual_f16, void* out_f16, int ldo, int vt_col0, void* outT,
                  int vt_ld, int vt_f32, int rows_per_batch, int force_cfg, int force_split);

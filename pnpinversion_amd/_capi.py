@@ -97,6 +97,7 @@ SYMBOLS = {
     "pnpi_op_conv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i]),
     "pnpi_op_conv_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _ip]),
     "pnpi_set_tuning": (_i, [C.c_char_p, _i]),
+    "pnpi_tile_table_lookup": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pnpi_op_gemm": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "pnpi_op_gemm_geglu": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
     "pnpi_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),

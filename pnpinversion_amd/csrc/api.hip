@@ -1764,6 +1764,9 @@ int pnpi_op_conv_stats(pnpi_ctx* c, const void* x1, const void* x2, int C1, int 
   return 0;
 }
 /* process-wide kernel tuning knobs (tile-variant A/B inside one process, tests of non-default variants) */
+int pnpi_tile_table_lookup(int M, int N, int K, int ksize, int* cfg, int* split, int* entry_m) {
+  return igemm_table_lookup(M, N, K, ksize, cfg, split, entry_m);
+}
 int pnpi_set_tuning(const char* key, int value) {
   if (!key) return PNPI_EINVAL;
   if (!strcmp(key, "text_kv")) { g_text_kv = value; return 0; }

@@ -900,6 +900,7 @@ static constexpr size_t ZERO_PAGE_BYTES = 128 << 10;   // >= 2 * (longest K + on
 static int g_wide = 1;      // PNPI_IGEMM_WIDE=0: never pick the 128x320 / 128x256 tiles (ablation)
 static int g_use_dma = 1;      // 0: register-staged v1 kernel everywhere
 static int g_use_table = 1;    // tuning "igemm_table" = 0: cost model only (no measured per-shape table)
+static int g_table_near = 1;   // tuning "igemm_table_near" = 0: exact {M, N, K, ksize} matches only (no nearest-row-count entry)
 static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in the store loop (fp16(fp16(acc + bias) + res)) instead of staged
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
@@ -914,7 +915,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -957,6 +958,29 @@ struct TileEntry { int M, N, K, ks, cfg, split; };
 static const TileEntry kTileTable[] = {
 #include "tile_table.inc"
 };
+// Table lookup: the exact {M, N, K, ksize}; else -- the same layer (N, K, ksize) at another row count, e.g. --batch_size 2 ... 7 of the
+// sweep driver -- the entry whose M is nearest in ratio, up to 4x away.  Held out of the table one row count at a time, the nearest
+// entry's configuration costs 13.3 / 10.1 / 6.7 / 5.2 ms per 12- / 8- / 4- / 3-row forward against 15.3 / 10.4 / 6.9 / 6.1 ms for the
+// cost model's pick (per-shape best 12.5 / 9.4 / 6.0 / 5.1; profiles/round2_fwd_tune_b*.json).  how: 1 exact, 2 nearest, 0 none.
+static const TileEntry* tile_table_lookup(int M, int N, int K, int ks, int* how) {
+  const TileEntry* near = nullptr;
+  double near_ratio = 4.0 + 1e-9;
+  for (const TileEntry& e : kTileTable) {
+    if (e.N != N || e.K != K || e.ks != ks) continue;
+    if (e.M == M) { if (how) *how = 1; return &e; }
+    const double r = e.M > M ? (double)e.M / M : (double)M / e.M;
+    if (r < near_ratio) { near_ratio = r; near = &e; }      // ties: the first (smaller M) entry of the sorted table
+  }
+  if (!g_table_near) near = nullptr;
+  if (how) *how = near ? 2 : 0;
+  return near;
+}
+int igemm_table_lookup(int M, int N, int K, int ks, int* cfg, int* split, int* entry_m) {
+  int how = 0;
+  const TileEntry* e = (M > 0 && N > 0 && K > 0) ? tile_table_lookup(M, N, K, ks, &how) : nullptr;
+  if (e) { if (cfg) *cfg = e->cfg; if (split) *split = e->split; if (entry_m) *entry_m = e->M; }
+  return how;
+}
 // cfg 6 = 256x320, 7 = 256x256 (8 waves, 128-byte rows, two stages, one block per CU); 8-11: K-parallel wave groups; 12 = 64x320;
 // 13 = 128x128 with a two-stage ring; 14 / 15 = 128x128 / 128x256 with 128-byte rows: reached through the table or force_cfg
 
@@ -976,14 +1000,13 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   int split = 1;
   if (cfg < 0 && g_force_cfg >= 0) { cfg = g_force_cfg == 2 ? 1 : g_force_cfg; if (force_split <= 0) force_split = g_force_split; }
   if (cfg < 0 && g_use_table && dma_ok) {
-    for (const TileEntry& e : kTileTable)
-      if (e.M == p.M && e.N == p.N && e.K == p.K && e.ks == p.ksize) {
+    if (const TileEntry* pe = tile_table_lookup(p.M, p.N, p.K, p.ksize, nullptr)) {
+        const TileEntry& e = *pe;
         const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12) ? 320 : ((e.cfg == 5 || e.cfg == 7 || e.cfg == 15) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
         const bool split_ok = e.split == 1 || (!p.geglu && ws && (size_t)e.split * p.M * p.N * sizeof(float) <= ws_bytes);
         const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
         if (split_ok && vt_ok && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14)) { cfg = e.cfg; split = e.split; }
-        break;
-      }
+    }
   }
   if (cfg < 0) {
     // Tile / split-K selection by a small cost model (constants fitted to per-shape timings on MI355X, tools/fit_cost_model.py):

@@ -38,6 +38,8 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
 int igemm_init();  // sets dynamic-LDS attributes once
 // tile configuration id / split-K of the most recent launch_igemm and the <BM, BN, BKT, NST, WGM, ABL, WK> of its igemm_dma_kernel (profiling)
 void igemm_last_launch(int* cfg, int* split, int* geom7);
+// measured tile table: 1 = exact {M, N, K, ksize} entry, 2 = the same layer at the nearest row count (<= 4x away in M), 0 = none (cost model)
+int igemm_table_lookup(int M, int N, int K, int ksize, int* cfg, int* split, int* entry_m);
 int igemm_set_tuning(const char* key, int value);   // process-wide tuning knobs; 0 on success, -1 unknown key
 void igemm_set_dma(int on);  // 1 (default): LDS-DMA kernel where applicable; 0: register-staged v1 kernel everywhere
 
