@@ -20,6 +20,8 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_proximal_recon.npz  the same method with use_reconstruction_guidance=True (masked pred-x0 pull + dilated edit mask), 4 steps
   e2e_null_text.npz    P2PEditor("null-text-inversion+p2p"): inversion latents, the optimised per-step unconditional embeddings, the loss
                        of every Adam iteration, reconstruction / edited latents (pins the oracle of the not-yet-built native path)
+  null_latent_tiny.npz DirectInversion.invert_null_latent (ablation_null-latent-inversion+p2p) on a 128 x 128 crop, TINY16 weights: inversion
+                       latents, per-step latent offsets, every Adam iteration's loss
   clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
   method_dispatch.json P2PEditor.__call__'s routing of its 39 method strings (handler + method-specific arguments)
 """
@@ -433,6 +435,40 @@ def null_text(steps=3):
     print("null_text %.1fs, %d inner iterations, loss %.3e -> %.3e" % (time.time() - t0, len(losses), losses[0], losses[-1]))
 
 
+def null_latent(steps=3):
+    """DirectInversion.invert_null_latent (inversion.py:418-470; the inversion of "ablation_null-latent-inversion+p2p") on a 128 x 128
+    crop (16 x 16 latents: the B = 2 optimisation through 4096-token attention maps would take minutes per step on CPU; the guidance
+    passes that consume the offsets are direct_inversion_p2p_guidance_forward, pinned by e2e_refine).  Pins p2p_oracle.null_latent_calculate."""
+    ref_shim.install()
+    cfg = TINY16
+    usd, vsd = weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, _, _ = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")).convert("RGB").resize((128, 128)))
+    import models.p2p.inversion as inv
+    losses = []
+    orig_mse = inv.nnf.mse_loss
+
+    def spy_mse(*a, **k):
+        r = orig_mse(*a, **k)
+        losses.append(float(r.detach()))
+        return r
+
+    inv.nnf.mse_loss = spy_mse
+    t0 = time.time()
+    try:
+        with ref_shim.cuda_to_cpu():
+            di = inv.DirectInversion(model=ed.ldm_stable, num_ddim_steps=steps)
+            _, _, x_stars, nl = di.invert_null_latent(image_gt=img, prompt=[src, tgt], guidance_scale=7.5)
+    finally:
+        inv.nnf.mse_loss = orig_mse
+    np.savez_compressed(os.path.join(OUT, "null_latent_tiny.npz"), x_stars=torch.stack([x.detach() for x in x_stars]).numpy(),
+                        noise_loss=torch.stack([x.detach() for x in nl]).numpy(), context=di.context.detach().numpy(),
+                        losses=np.array(losses, dtype=np.float64), steps=np.int64(steps), src=src, tgt=tgt)
+    print("null_latent %.1fs, %d inner iterations, |offset| %.3e" % (time.time() - t0, len(losses), float(torch.stack(nl).abs().mean())))
+
+
 def masactrl(steps=6, start_step=2, start_layer=10):
     """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -526,6 +562,8 @@ if __name__ == "__main__":
         proximal_recon()
     if "null_text" in which or not sys.argv[1:]:
         null_text()
+    if "null_latent" in which or not sys.argv[1:]:
+        null_latent()
     if "clip" in which:
         clip_text()
     if "dispatch" in which:

@@ -316,3 +316,30 @@ def test_null_text_optimization_matches_reference():
         ctrl = po.EditController(32, _tables_from_product(gg, steps))
         out = po.guidance_forward(unet_fn, x_stars[-1], torch.cat([ctx2[:1], ctx2[:1], text]), None, ctrl, ts, ac_, ac_[0], 7.5, uncond_list=ul)
         assert rel(out, g["edited_latents"]) < 5e-5, rel(out, g["edited_latents"])
+
+
+def test_null_latent_offsets_match_reference():
+    """DirectInversion.invert_null_latent (inversion.py:418-470, "ablation_null-latent-inversion+p2p") against the oracle's
+    null_latent_calculate: inversion latents, all 30 Adam iterations' losses and the three per-step latent offsets (128 x 128 crop,
+    TINY16 weights).  Like null-text inversion the native path does not build this method yet; this pins its checker."""
+    g = load("null_latent_tiny.npz")
+    cfg, steps = TINY16, int(g["steps"])
+    usd = weights.unet_state_dict(cfg, 1)
+    ctx4 = torch.from_numpy(g["context"]).float()                    # ["", "", source, target]
+    x_stars = torch.from_numpy(g["x_stars"])
+    ac_, ts = po.alphas_cumprod(), po.make_timesteps(steps)
+
+    def unet_fn(lat, t, c, hook):
+        return sd_oracle.unet_forward(usd, cfg, lat, t, c, hook)
+
+    with torch.no_grad():
+        lat = po.ddim_loop(unet_fn, x_stars[0], ctx4[2:3], ts, ac_, ac_[0])
+    assert rel(torch.stack(lat), x_stars) < 2e-5
+    trace = []
+    nl = po.null_latent_calculate(unet_fn, [x for x in x_stars], ctx4, ts, ac_, ac_[0], 7.5, num_inner_steps=10, epsilon=1e-5, trace=trace)
+    got_losses = [l for _, ls in trace for l in ls]
+    assert len(got_losses) == len(g["losses"]) == 30
+    assert np.allclose(got_losses, g["losses"], rtol=2e-4)
+    ref = torch.from_numpy(g["noise_loss"])
+    assert rel(torch.stack(nl), ref) < 5e-4, rel(torch.stack(nl), ref)
+    assert ref.abs().mean() > 1e-2 and rel(torch.stack(nl)[:, 1], ref[:, 0]) > 1e-2      # real offsets; source and target rows differ
