@@ -283,6 +283,26 @@ int pnpi_op_groupnorm(pnpi_ctx* ctx, const void* x1, const void* x2, int C1, int
 int pnpi_op_layernorm(pnpi_ctx* ctx, const void* x, int M, int C, float eps, const float* gamma, const float* beta, void* out);
 int pnpi_op_geglu(pnpi_ctx* ctx, const void* x, int M, int inner, void* out);
 int pnpi_op_softmax_rows(pnpi_ctx* ctx, void* x, int M, int N, int ld);
+/* Activation-gradient kernels of the null-text / null-latent path (NullInversion.null_optimization's loss.backward(), inversion.py:
+ * 196-225) -- groundwork, kernel-level only (no method string reaches them yet).  fp16 tensors in the forward's layouts.
+ *   layernorm_bwd: dx of torch.nn.LayerNorm from the saved input;  groupnorm_bwd: dx (dense [B][HW][C1+C2]) of GroupNorm(+SiLU) over the
+ *   virtual concat (x1, x2);  geglu_bwd: d(projection) in the interleaved [x(32)|gate(32)] layout;  softmax_bwd_rows: dS = scale * P *
+ *   (dP - rowsum(dP * P)) as fp16 rows padded to ld;  accumulate: dst += src;  sumpool2x2: nearest-2x upsample backward;  zero_stuff2 +
+ *   repack_dgrad: stride-2 / stride-1 convolution dgrad through the forward kernel (wd[c][k*k-1-tap][n] = w[n][tap][c]);
+ *   null_text_loss: mse(prev_step(cfg(eps_u, eps_c)), target) and its gradient w.r.t. eps_u (times grad_scale);  adam_step: torch.optim.Adam
+ *   defaults, step k >= 1, gradient times inv_scale. */
+int pnpi_op_layernorm_bwd(pnpi_ctx* ctx, const void* x, const void* dy, int M, int C, float eps, const float* gamma, void* dx);
+int pnpi_op_groupnorm_bwd(pnpi_ctx* ctx, const void* x1, const void* x2, int C1, int C2, int B, int HW, int groups, float eps,
+                          const float* gamma, const float* beta, int silu, const void* dy, void* dx);
+int pnpi_op_geglu_bwd(pnpi_ctx* ctx, const void* h, const void* dy, int M, int inner, void* dh);
+int pnpi_op_softmax_bwd_rows(pnpi_ctx* ctx, const float* P, const float* dP, int R, int N, int ld, float scale, void* dS);
+int pnpi_op_accumulate(pnpi_ctx* ctx, void* dst, const void* src, size_t n);
+int pnpi_op_sumpool2x2(pnpi_ctx* ctx, const void* dup, int B, int H, int W, int C, void* dx);
+int pnpi_op_zero_stuff2(pnpi_ctx* ctx, const void* dy, int B, int Ho, int Wo, int C, void* out);
+int pnpi_op_repack_dgrad(pnpi_ctx* ctx, const void* w, int N, int taps, int Cin, void* wd);
+int pnpi_op_null_text_loss(pnpi_ctx* ctx, const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w,
+                           float c_x, float c_e, float grad_scale, void* d_eps_u, float* loss);
+int pnpi_op_adam_step(pnpi_ctx* ctx, float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale);
 int pnpi_op_attention(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
                       int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
                       const int* rows_dev /*[nrows][4]*/, int nrows);

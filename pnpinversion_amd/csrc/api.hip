@@ -1810,6 +1810,49 @@ int pnpi_op_softmax_rows(pnpi_ctx* c, void* x, int M, int N, int ld) {
   CK(launch_softmax_rows((half_t*)x, M, N, ld, c->st));
   return 0;
 }
+// ---- activation-gradient kernels (null-text path groundwork; tests/test_gpu_backward.py)
+int pnpi_op_layernorm_bwd(pnpi_ctx* c, const void* x, const void* dy, int M, int C, float eps, const float* gamma, void* dx) {
+  CK(launch_layernorm_bwd((const half_t*)x, (const half_t*)dy, M, C, eps, gamma, (half_t*)dx, c->st));
+  return 0;
+}
+int pnpi_op_groupnorm_bwd(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                          const float* beta, int silu, const void* dy, void* dx) {
+  CK(launch_groupnorm_bwd((const half_t*)x1, (const half_t*)x2, C1, C2, B, HW, G, eps, gamma, beta, silu, (const half_t*)dy, (half_t*)dx, c->st));
+  return 0;
+}
+int pnpi_op_geglu_bwd(pnpi_ctx* c, const void* h, const void* dy, int M, int inner, void* dh) {
+  CK(launch_geglu_bwd((const half_t*)h, (const half_t*)dy, M, inner, (half_t*)dh, c->st));
+  return 0;
+}
+int pnpi_op_softmax_bwd_rows(pnpi_ctx* c, const float* P, const float* dP, int R, int N, int ld, float scale, void* dS) {
+  CK(launch_softmax_bwd_rows(P, dP, (size_t)R, N, ld, scale, (half_t*)dS, c->st));
+  return 0;
+}
+int pnpi_op_accumulate(pnpi_ctx* c, void* dst, const void* src, size_t n) {
+  CK(launch_accumulate_f16((half_t*)dst, (const half_t*)src, n, c->st));
+  return 0;
+}
+int pnpi_op_sumpool2x2(pnpi_ctx* c, const void* dup, int B, int H, int W, int C, void* dx) {
+  CK(launch_sumpool2x2((const half_t*)dup, B, H, W, C, (half_t*)dx, c->st));
+  return 0;
+}
+int pnpi_op_zero_stuff2(pnpi_ctx* c, const void* dy, int B, int Ho, int Wo, int C, void* out) {
+  CK(launch_zero_stuff2((const half_t*)dy, B, Ho, Wo, C, (half_t*)out, c->st));
+  return 0;
+}
+int pnpi_op_repack_dgrad(pnpi_ctx* c, const void* w, int N, int taps, int Cin, void* wd) {
+  CK(launch_repack_dgrad((const half_t*)w, N, taps, Cin, (half_t*)wd, c->st));
+  return 0;
+}
+int pnpi_op_null_text_loss(pnpi_ctx* c, const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x,
+                           float c_e, float grad_scale, void* d_eps_u, float* loss) {
+  CK(launch_null_text_loss(eps_u, eps_c, x, target, n, w, c_x, c_e, grad_scale, (half_t*)d_eps_u, loss, c->st));
+  return 0;
+}
+int pnpi_op_adam_step(pnpi_ctx* c, float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale) {
+  CK(launch_adam_step(p, m, v, g, n, k, lr, inv_scale, c->st));
+  return 0;
+}
 int pnpi_op_attention(pnpi_ctx* c, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt, int ldv,
                       void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, const int* rows_dev, int nrows) {
   AttnP a; a.q = (const half_t*)q; a.ldq = ldq; a.q_off = q_off; a.k = (const half_t*)k; a.ldk = ldk; a.k_off = k_off;
