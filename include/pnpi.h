@@ -303,6 +303,14 @@ int pnpi_op_repack_dgrad(pnpi_ctx* ctx, const void* w, int N, int taps, int Cin,
 int pnpi_op_null_text_loss(pnpi_ctx* ctx, const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w,
                            float c_x, float c_e, float grad_scale, void* d_eps_u, float* loss);
 int pnpi_op_adam_step(pnpi_ctx* ctx, float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale);
+/* Attention backward (CrossAttention.forward of my_diffusers/models/attention.py:217-259 differentiated), materialised per (row, head):
+ * q / k / v are [B*N][ld] fp16 views with head h at columns off + h * Dp (dh real columns, pad columns zero), d_o is [B*Nq][ldo] with
+ * heads * dh columns; dq / dk / dv receive the gradients in the layout of q / k / v (pad columns untouched).  scratch: device memory
+ * of at least pnpi_op_attention_bwd_scratch_bytes(Nq, Nk, dh) bytes. */
+int pnpi_op_attention_bwd(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* v, int ldv,
+                          int v_off, const void* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, void* dq,
+                          void* dk, void* dv, void* scratch, size_t scratch_bytes);
+size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh);
 int pnpi_op_attention(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
                       int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
                       const int* rows_dev /*[nrows][4]*/, int nrows);

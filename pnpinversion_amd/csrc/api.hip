@@ -1810,6 +1810,68 @@ int pnpi_op_softmax_rows(pnpi_ctx* c, void* x, int M, int N, int ld) {
   CK(launch_softmax_rows((half_t*)x, M, N, ld, c->st));
   return 0;
 }
+// Attention backward, materialised per (row, head) like the call-back path's forward (first version: generic GEMM launches and
+// transposes; a fused flash backward replaces it later).  q / k: [B*N][ld] views with the head's columns at off + h * Dp (pad columns
+// dh .. Dp are zero, as the forward guarantees); v: plain [B*Nk][ldvp] with the same head layout; d_o: [B*Nq][ldo], heads * dh wide.
+// Outputs dq / dk / dv in the layout of q / k / v (their pad columns are left untouched: clear the buffers first).
+//   S = scale q k^T, P = softmax(S);  dV = P^T dO;  dP = dO V^T;  dS = scale P (dP - rowsum(dP P));  dQ = dS K;  dK = dS^T Q.
+// scratch: Nq * Nk * 8 (S / P and dP, fp32) + 2 * Nq * ldp * 2 (P, dS as fp16) + 2 * Nk * ldq8 * 2 (their transposes) + dh * (ldp + 2 * ldq8) * 2
+// bytes (K^T, Q^T, dO^T), reused for every (row, head).
+static size_t attn_bwd_scratch_bytes(int Nq, int Nk, int dh) {
+  const size_t ldp = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
+  return align_up((size_t)Nq * Nk * 4, 256) * 2 + align_up((size_t)Nq * ldp * 2, 256) * 2 + align_up((size_t)Nk * ldq8 * 2, 256) * 2 +
+         align_up((size_t)dh * ldp * 2, 256) + align_up((size_t)dh * ldq8 * 2, 256) * 2;
+}
+static int attn_bwd_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp,
+                                 int v_off, const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B,
+                                 half_t* dq, half_t* dk, half_t* dv, void* scratch, size_t scratch_bytes) {
+  if (!scratch || scratch_bytes < attn_bwd_scratch_bytes(Nq, Nk, dh)) return fail(c, PNPI_ENOMEM, "attention backward scratch too small");
+  if ((dh & 7) || (ldq & 7) || (ldk & 7) || (ldvp & 7) || (ldo & 7)) return fail(c, PNPI_ESHAPE, "attention backward: extents must be multiples of 8");
+  const int ldp = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
+  char* sp = (char*)scratch;
+  auto take = [&](size_t bytes) { char* r = sp; sp += align_up(bytes, 256); return r; };
+  float* S = (float*)take((size_t)Nq * Nk * 4);
+  float* dP = (float*)take((size_t)Nq * Nk * 4);
+  half_t* P16 = (half_t*)take((size_t)Nq * ldp * 2);
+  half_t* dS16 = (half_t*)take((size_t)Nq * ldp * 2);
+  half_t* PT = (half_t*)take((size_t)Nk * ldq8 * 2);
+  half_t* dST = (half_t*)take((size_t)Nk * ldq8 * 2);
+  half_t* Kt = (half_t*)take((size_t)dh * ldp * 2);
+  half_t* Qt = (half_t*)take((size_t)dh * ldq8 * 2);
+  half_t* dOt = (half_t*)take((size_t)dh * ldq8 * 2);
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < heads; ++h) {
+      const half_t* qh = q + (size_t)b * Nq * ldq + q_off + h * Dp;
+      const half_t* kh = k + (size_t)b * Nk * ldk + k_off + h * Dp;
+      const half_t* vh = v + (size_t)b * Nk * ldvp + v_off + h * Dp;
+      const half_t* doh = d_o + (size_t)b * Nq * ldo + h * dh;
+      VtOut vs; vs.outT = S; vs.col0 = 0; vs.ld = Nk; vs.f32 = 1; vs.rpb = Nk;            // S[q][key] = scale * sum_d k[key][d] q[q][d]
+      CK(op_gemm(c, kh, ldk, Nk, dh, qh, ldq, Nq, nullptr, nullptr, 0, nullptr, Nq, scale, &vs));
+      CK(launch_softmax_rows_f32(S, (size_t)Nq, Nk, c->st));
+      VtOut vp; vp.outT = dP; vp.col0 = 0; vp.ld = Nk; vp.f32 = 1; vp.rpb = Nk;          // dP[q][key] = sum_d v[key][d] dO[q][d]
+      CK(op_gemm(c, vh, ldvp, Nk, dh, doh, ldo, Nq, nullptr, nullptr, 0, nullptr, Nq, 1.f, &vp));
+      CK(launch_f32_rows_to_f16_padded(S, (size_t)Nq, Nk, ldp, P16, c->st));
+      CK(launch_softmax_bwd_rows(S, dP, (size_t)Nq, Nk, ldp, scale, dS16, c->st));
+      CK(launch_transpose_f16(P16, ldp, Nq, Nk, PT, ldq8, c->st));
+      CK(launch_transpose_f16(dS16, ldp, Nq, Nk, dST, ldq8, c->st));
+      CK(launch_transpose_f16(kh, ldk, Nk, dh, Kt, ldp, c->st));
+      CK(launch_transpose_f16(qh, ldq, Nq, dh, Qt, ldq8, c->st));
+      CK(launch_transpose_f16(doh, ldo, Nq, dh, dOt, ldq8, c->st));
+      CK(op_gemm(c, dS16, ldp, Nq, ldp, Kt, ldp, dh, nullptr, nullptr, 0, dq + (size_t)b * Nq * ldq + q_off + h * Dp, ldq));        // dQ = dS K
+      CK(op_gemm(c, dST, ldq8, Nk, ldq8, Qt, ldq8, dh, nullptr, nullptr, 0, dk + (size_t)b * Nk * ldk + k_off + h * Dp, ldk));      // dK = dS^T Q
+      CK(op_gemm(c, PT, ldq8, Nk, ldq8, dOt, ldq8, dh, nullptr, nullptr, 0, dv + (size_t)b * Nk * ldvp + v_off + h * Dp, ldvp));    // dV = P^T dO
+    }
+  return 0;
+}
+int pnpi_op_attention_bwd(pnpi_ctx* c, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* v, int ldv, int v_off,
+                          const void* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, void* dq, void* dk, void* dv,
+                          void* scratch, size_t scratch_bytes) {
+  if (!c || !q || !k || !v || !d_o || !dq || !dk || !dv) return PNPI_EINVAL;
+  CKP(attn_bwd_materialized(c, (const half_t*)q, ldq, q_off, (const half_t*)k, ldk, k_off, (const half_t*)v, ldv, v_off, (const half_t*)d_o, ldo,
+                            heads, Nq, Nk, Dp, dh, scale, B, (half_t*)dq, (half_t*)dk, (half_t*)dv, scratch, scratch_bytes));
+  return 0;
+}
+size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh) { return attn_bwd_scratch_bytes(Nq, Nk, dh); }
 // ---- activation-gradient kernels (null-text path groundwork; tests/test_gpu_backward.py)
 int pnpi_op_layernorm_bwd(pnpi_ctx* c, const void* x, const void* dy, int M, int C, float eps, const float* gamma, void* dx) {
   CK(launch_layernorm_bwd((const half_t*)x, (const half_t*)dy, M, C, eps, gamma, (half_t*)dx, c->st));

@@ -320,6 +320,31 @@ int launch_repack_dgrad(const half_t* w, int N, int taps, int Cin, half_t* wd, h
   return (int)hipGetLastError();
 }
 
+// dst[c][r] = src[r][c] for r < R, c < Cc; dst rows are ld_dst long and zero beyond R (GEMM operands need their k-extent padded to 8).
+// 32 x 32 tiles through LDS (+1 padding), 256 threads.
+__global__ void __launch_bounds__(256) transpose_f16_kernel(const half_t* __restrict__ src, int ld_src, int R, int Cc, half_t* __restrict__ dst,
+                                                            int ld_dst) {
+  __shared__ half_t tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < Cc) ? src[(size_t)r * ld_src + c] : (half_t)0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < Cc && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][ty + 8 * i];
+  }
+}
+int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st) {
+  if (R <= 0 || Cc <= 0 || ld_dst < R) return -3;
+  transpose_f16_kernel<<<dim3((ld_dst + 31) / 32, (Cc + 31) / 32), 256, 0, st>>>(src, ld_src, R, Cc, dst, ld_dst);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ loss head and Adam
 // NullInversion.null_optimization's inner iteration (inversion.py:209-218) around the UNet:
 //   eps = eps_u + w (eps_c - eps_u);  rec = c_x x + c_e eps  (prev_step with its two scalars folded by the caller);

@@ -147,3 +147,4 @@ int launch_repack_dgrad(const half_t* w, int N, int taps, int Cin, half_t* wd, h
 int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x, float c_e,
                           float grad_scale, half_t* d_eps_u, float* loss, hipStream_t st);
 int launch_adam_step(float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale, hipStream_t st);
+int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st);

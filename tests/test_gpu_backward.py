@@ -156,3 +156,31 @@ def test_null_text_loss_head_and_adam(ctx):
         gs = (gk * scale).contiguous()
         ctx.call("pnpi_op_adam_step", ptr(p), ptr(m), ptr(v), ptr(gs), p.numel(), k, 1e-2 * (1 - 3 / 100.0), 1.0 / scale)
         assert (p - pr.detach()).abs().max().item() < 2e-6, (k, (p - pr.detach()).abs().max().item())
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,dh,Dp", [(1, 2, 64, 77, 40, 64), (2, 8, 256, 256, 8, 32), (1, 8, 1024, 1024, 40, 64), (1, 4, 4, 77, 160, 160)])
+def test_attention_bwd_materialised(ctx, B, heads, Nq, Nk, dh, Dp):
+    """dq / dk / dv of softmax(scale q k^T) v per (row, head) -- self-attention shapes and the 77-key cross-attention -- against autograd."""
+    g = torch.Generator(device="cpu").manual_seed(20)
+    scale = 1.0 / math.sqrt(dh)
+
+    def padded(n):
+        t = torch.zeros(B, n, heads, Dp)
+        t[..., :dh] = torch.randn(B, n, heads, dh, generator=g)
+        return t.reshape(B * n, heads * Dp).half().to(DEV)
+
+    q, k, v = padded(Nq), padded(Nk), padded(Nk)
+    d_o = torch.randn(B * Nq, heads * dh, generator=g).half().to(DEV)
+    qr, kr, vr = [t.float().reshape(B, -1, heads, Dp)[..., :dh].permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v)]
+    o = torch.softmax(scale * qr @ kr.transpose(-1, -2), -1) @ vr                         # [B, heads, Nq, dh]
+    o.backward(d_o.float().reshape(B, Nq, heads, dh).permute(0, 2, 1, 3))
+    dq, dk, dv = [torch.zeros_like(t) for t in (q, k, v)]
+    nbytes = ctx.lib.pnpi_op_attention_bwd_scratch_bytes(Nq, Nk, dh)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    ctx.call("pnpi_op_attention_bwd", ptr(q), heads * Dp, 0, ptr(k), heads * Dp, 0, ptr(v), heads * Dp, 0, ptr(d_o), heads * dh, heads, Nq, Nk, Dp, dh,
+             scale, B, ptr(dq), ptr(dk), ptr(dv), ptr(scratch), nbytes)
+    torch.cuda.synchronize()
+    for got, ref, n in ((dq, qr.grad, Nq), (dk, kr.grad, Nk), (dv, vr.grad, Nk)):
+        gh = got.float().reshape(B, n, heads, Dp)
+        assert (gh[..., dh:] == 0).all()                                                  # pad columns untouched
+        assert rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref) < 6e-3, rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref)
