@@ -20,6 +20,10 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_proximal_recon.npz  the same method with use_reconstruction_guidance=True (masked pred-x0 pull + dilated edit mask), 4 steps
   e2e_null_text.npz    P2PEditor("null-text-inversion+p2p"): inversion latents, the optimised per-step unconditional embeddings, the loss
                        of every Adam iteration, reconstruction / edited latents (pins the oracle of the not-yet-built native path)
+  null_text_family_tiny.npz  the edit passes of null-text-inversion+p2p / ..._single_branch+p2p / null-text-inversion+proximal-guidance on a
+                       128 x 128 crop (TINY16 weights, AttentionRefine): per-step embeddings on every / the first unconditional row, l0 proximal step
+  null_latent_tiny.npz DirectInversion.invert_null_latent (ablation_null-latent-inversion+p2p) on a 128 x 128 crop, TINY16 weights: inversion
+                       latents, per-step latent offsets, every Adam iteration's loss
   clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
   method_dispatch.json P2PEditor.__call__'s routing of its 39 method strings (handler + method-specific arguments)
 """
@@ -433,6 +437,94 @@ def null_text(steps=3):
     print("null_text %.1fs, %d inner iterations, loss %.3e -> %.3e" % (time.time() - t0, len(losses), losses[0], losses[-1]))
 
 
+def null_latent(steps=3):
+    """DirectInversion.invert_null_latent (inversion.py:418-470; the inversion of "ablation_null-latent-inversion+p2p") on a 128 x 128
+    crop (16 x 16 latents: the B = 2 optimisation through 4096-token attention maps would take minutes per step on CPU; the guidance
+    passes that consume the offsets are direct_inversion_p2p_guidance_forward, pinned by e2e_refine).  Pins p2p_oracle.null_latent_calculate."""
+    ref_shim.install()
+    cfg = TINY16
+    usd, vsd = weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, _, _ = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")).convert("RGB").resize((128, 128)))
+    import models.p2p.inversion as inv
+    losses = []
+    orig_mse = inv.nnf.mse_loss
+
+    def spy_mse(*a, **k):
+        r = orig_mse(*a, **k)
+        losses.append(float(r.detach()))
+        return r
+
+    inv.nnf.mse_loss = spy_mse
+    t0 = time.time()
+    try:
+        with ref_shim.cuda_to_cpu():
+            di = inv.DirectInversion(model=ed.ldm_stable, num_ddim_steps=steps)
+            _, _, x_stars, nl = di.invert_null_latent(image_gt=img, prompt=[src, tgt], guidance_scale=7.5)
+    finally:
+        inv.nnf.mse_loss = orig_mse
+    np.savez_compressed(os.path.join(OUT, "null_latent_tiny.npz"), x_stars=torch.stack([x.detach() for x in x_stars]).numpy(),
+                        noise_loss=torch.stack([x.detach() for x in nl]).numpy(), context=di.context.detach().numpy(),
+                        losses=np.array(losses, dtype=np.float64), steps=np.int64(steps), src=src, tgt=tgt)
+    print("null_latent %.1fs, %d inner iterations, |offset| %.3e" % (time.time() - t0, len(losses), float(torch.stack(nl).abs().mean())))
+
+
+def null_text_family(steps=3):
+    """The other consumers of null-text embeddings, on a 128 x 128 crop with TINY16 weights (16 x 16 latents; AttentionRefine without
+    LocalBlend, whose 16 x 16 attention maps do not exist at this size; the loops' hard-coded 512 in the init_latent call is overridden by the
+    latent's own size): NullInversion.invert, then the edit pass of
+      "null-text-inversion+p2p"                          p2p_guidance_forward               (the embedding on every unconditional row)
+      "ablation_null-text-inversion_single_branch+p2p"   p2p_guidance_forward_single_branch (on the first row only)
+      "null-text-inversion+proximal-guidance"            proximal_guidance_forward with the sweep script's arguments (l0, quantile 0.75)."""
+    ref_shim.install()
+    cfg = TINY16
+    usd, vsd = weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    model = ed.ldm_stable
+    src, tgt, _, _ = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")).convert("RGB").resize((128, 128)))
+    from models.p2p.inversion import NullInversion
+    from models.p2p.p2p_guidance_forward import p2p_guidance_forward, p2p_guidance_forward_single_branch
+    from models.p2p.proximal_guidance_forward import proximal_guidance_forward
+    from models.p2p.attention_control import make_controller
+    import models.p2p.p2p_guidance_forward as gf
+    import models.p2p.proximal_guidance_forward as pf
+    orig_init = gf.init_latent
+
+    def init_latent_any_size(latent, model_, height, width, generator, batch_size):
+        # the guidance loops hard-code height = width = 512 for utils.init_latent's expand(); everything else in them is size-agnostic
+        return orig_init(latent, model_, 8 * latent.shape[-2], 8 * latent.shape[-1], generator, batch_size)
+
+    gf.init_latent = pf.init_latent = init_latent_any_size
+    t0 = time.time()
+    out = {"steps": np.int64(steps), "src": src, "tgt": tgt}
+    with ref_shim.cuda_to_cpu():
+        ni = NullInversion(model=model, num_ddim_steps=steps)
+        _, _, x_stars, unc = ni.invert(image_gt=img, prompt=src, guidance_scale=7.5)
+        out["x_stars"] = torch.stack([x.detach() for x in x_stars]).numpy()
+        out["uncond_embeddings"] = torch.stack([u.detach() for u in unc]).numpy()
+        out["context"] = ni.context.detach().numpy()
+
+        def ctrl():
+            return make_controller(pipeline=model, prompts=[src, tgt], is_replace_controller=False, cross_replace_steps={"default_": 0.4},
+                                   self_replace_steps=0.6, blend_words=None, equilizer_params=None, num_ddim_steps=steps, device="cpu")
+        x_t = x_stars[-1]
+        out["p2p/edited_latents"] = p2p_guidance_forward(model=model, prompt=[src, tgt], controller=ctrl(), latent=x_t, num_inference_steps=steps,
+                                                         guidance_scale=7.5, generator=None, uncond_embeddings=unc)[0].numpy()
+        out["single_branch/edited_latents"] = p2p_guidance_forward_single_branch(
+            model=model, prompt=[src, tgt], controller=ctrl(), latent=x_t, num_inference_steps=steps, guidance_scale=7.5, generator=None,
+            uncond_embeddings=unc)[0].numpy()
+        out["proximal/edited_latents"] = proximal_guidance_forward(
+            model=model, prompt=[src, tgt], controller=ctrl(), latent=x_t, guidance_scale=7.5, generator=None, uncond_embeddings=unc,
+            edit_stage=True, prox="l0", quantile=0.75, image_enc=None, recon_lr=1, recon_t=400, x_stars=x_stars, dilate_mask=1)[0].numpy()
+    gf.init_latent = pf.init_latent = orig_init
+    np.savez_compressed(os.path.join(OUT, "null_text_family_tiny.npz"), **out)
+    print("null_text_family %.1fs" % (time.time() - t0), {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def masactrl(steps=6, start_step=2, start_layer=10):
     """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -526,6 +618,10 @@ if __name__ == "__main__":
         proximal_recon()
     if "null_text" in which or not sys.argv[1:]:
         null_text()
+    if "null_latent" in which or not sys.argv[1:]:
+        null_latent()
+    if "null_text_family" in which or not sys.argv[1:]:
+        null_text_family()
     if "clip" in which:
         clip_text()
     if "dispatch" in which:

@@ -369,6 +369,60 @@ def null_optimization(unet_fn, ddim_latents, ctx_uncond, ctx_cond, timesteps, ac
     return out
 
 
+def _adam_update(p, g, m, v, k, lr):
+    """torch.optim.Adam defaults, step k >= 1 (see null_optimization)."""
+    m = 0.9 * m + 0.1 * g
+    v = 0.999 * v + 0.001 * g * g
+    denom = (v.sqrt() / (1 - 0.999 ** k) ** 0.5) + 1e-8
+    return (p - (lr / (1 - 0.9 ** k)) * (m / denom)).detach(), m, v
+
+
+def null_latent_calculate(unet_fn, ddim_latents, context4, timesteps, ac, final, guidance_scale, num_inner_steps=10, epsilon=1e-5,
+                          trace=None):
+    """DirectInversion.null_latent_calculate (inversion.py:418-460; "ablation_null-latent-inversion+p2p"): per step the unconditional
+    embeddings of BOTH prompts are optimised like null-text inversion (one B = 2 CFG forward per Adam iteration, the loss on the SOURCE
+    row only, so the target row's embedding receives a zero gradient and stays put), then the step's effect is converted into a latent
+    offset: noise_loss[i] = prev_step(CFG with the optimised embeddings) - prev_step(CFG with the original ones), and the walk continues
+    from the optimised step.  context4 rows = [unc_src, unc_tgt, cond_src, cond_tgt].  Returns the list of [2, 4, h, w] offsets."""
+    n = len(timesteps)
+    ratio = len(ac) // n
+    nrow = context4.shape[0] // 2
+    uncond, cond = context4[:nrow].clone(), context4[nrow:]
+    latent_cur = torch.cat([ddim_latents[-1]] * nrow)
+    out = []
+    for i in range(n):
+        t = int(timesteps[i])
+        a_t, a_p = prev_alphas(ac, final, t, ratio)
+        latent_prev = ddim_latents[len(ddim_latents) - i - 2]
+        losses = []
+        if num_inner_steps != 0:
+            uncond = uncond.clone().detach()
+            lr = 1e-2 * (1.0 - i / 100.0)
+            m, v = torch.zeros_like(uncond), torch.zeros_like(uncond)
+            for j in range(num_inner_steps):
+                u = uncond.clone().detach().requires_grad_(True)
+                with torch.enable_grad():
+                    eps = unet_fn(torch.cat([latent_cur] * 2), t, torch.cat([u, cond]), None)
+                    eu, ec = eps.chunk(2)
+                    rec = ddim_move(latent_cur, eu + guidance_scale * (ec - eu), float(a_t), float(a_p))
+                    loss = F.mse_loss(rec[:1], latent_prev)
+                g, = torch.autograd.grad(loss, u)
+                uncond, m, v = _adam_update(uncond, g, m, v, j + 1, lr)
+                losses.append(float(loss.detach()))
+                if losses[-1] < epsilon + i * 2e-5:
+                    break
+        with torch.no_grad():
+            eu, ec = unet_fn(torch.cat([latent_cur] * 2), t, context4, None).chunk(2)
+            plain = ddim_move(latent_cur, eu + guidance_scale * (ec - eu), float(a_t), float(a_p))
+            eu, ec = unet_fn(torch.cat([latent_cur] * 2), t, torch.cat([uncond, cond]), None).chunk(2)
+            opt = ddim_move(latent_cur, eu + guidance_scale * (ec - eu), float(a_t), float(a_p))
+        out.append((opt - plain).detach())
+        latent_cur = plain + out[-1]
+        if trace is not None:
+            trace.append((i, losses))
+    return out
+
+
 def image2latent(vae_encode_mean_fn, image_u8):
     """utils/utils.py:68-80"""
     x = torch.from_numpy(image_u8).float() / 127.5 - 1

@@ -1,4 +1,5 @@
-"""Debug helper: per-site attention probabilities of the materialise-and-call-back path vs the CPU oracle's."""
+"""Checker script (GPU box; lives under tests/ because it uses the oracle): per-site attention probabilities of the materialise-and-call-back
+path vs the CPU oracle's, all 32 sites.  usage: python tests/cb_sites_check.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pnpinversion_amd import weights
