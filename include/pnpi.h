@@ -311,6 +311,20 @@ int pnpi_op_attention_bwd(pnpi_ctx* ctx, const void* q, int ldq, int q_off, cons
                           int v_off, const void* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, void* dq,
                           void* dk, void* dv, void* scratch, size_t scratch_bytes);
 size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh);
+
+/* ---- differentiable UNet forward (null-text path; groundwork) ---------------------------------------------------------------
+ * pnpi_unet_context_grad: eps = unet(latents [1][4][h][w], t, context [1][77][768]) with every activation recorded, then the reverse
+ * walk: d_context_out [77][768] = (d eps / d context)^T d_eps for the given d loss / d eps (fp32 in the layout of eps; multiply it by
+ * a power-of-two loss scale -- activation gradients travel in fp16 -- and divide d_context_out by it).  eps_out nullable.
+ * pnpi_null_text_optimize: NullInversion.null_optimization (models/p2p/inversion.py:196-225) for one image: ddim_latents
+ * [nsteps + 1][4*h*w] (x*_0 first), the "" and the source-prompt embeddings, the denoising timesteps; uncond_out [nsteps][77][768]
+ * (the optimised embedding of every step), iters_out [nsteps] (nullable: Adam iterations run per step).  Context needs
+ * max_unet_rows large enough for one row's activations kept without reuse (12 is). */
+int pnpi_unet_context_grad(pnpi_ctx* ctx, const float* latents, int t, const float* context, const float* d_eps, float* eps_out,
+                           float* d_context_out);
+int pnpi_null_text_optimize(pnpi_ctx* ctx, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,
+                            const int* timesteps_host, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out,
+                            int* iters_out_host);
 int pnpi_op_attention(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
                       int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
                       const int* rows_dev /*[nrows][4]*/, int nrows);

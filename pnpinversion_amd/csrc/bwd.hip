@@ -244,6 +244,40 @@ int launch_accumulate_f16(half_t* dst, const half_t* src, size_t n, hipStream_t 
   return (int)hipGetLastError();
 }
 
+// dst[r][0 .. C) (+)= src[r * ld + off + 0 .. C): the two halves of a dense concat gradient go back to the two source tensors
+__global__ void __launch_bounds__(256) strided_add_f16_kernel(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld, int off, size_t R, int C,
+                                                              int accumulate) {
+  const int C8 = C >> 3;
+  const size_t total = R * C8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = idx / C8;
+    const int cv = (int)(idx - r * C8);
+    half8 v = ldg_half8(src + r * ld + off + cv * 8);
+    if (accumulate) {
+      const half8 a = ldg_half8(dst + r * C + cv * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)a[j] + (float)v[j]);
+    }
+    *reinterpret_cast<half8*>(dst + r * C + cv * 8) = v;
+  }
+}
+int launch_strided_add_f16(half_t* dst, const half_t* src, int ld, int off, size_t R, int C, int accumulate, hipStream_t st) {
+  if ((C & 7) || (ld & 7) || (off & 7)) return -3;
+  const size_t total = R * (C >> 3);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  strided_add_f16_kernel<<<blocks, 256, 0, st>>>(dst, src, ld, off, R, C, accumulate);
+  return (int)hipGetLastError();
+}
+// dst (fp32) += scale * src (fp16): the context gradient is summed over the 16 cross-attention layers in fp32
+__global__ void __launch_bounds__(256) add_f16_to_f32_kernel(float* __restrict__ dst, const half_t* __restrict__ src, size_t n, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += scale * (float)src[i];
+}
+int launch_add_f16_to_f32(float* dst, const half_t* src, size_t n, float scale, hipStream_t st) {
+  int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+  add_f16_to_f32_kernel<<<blocks, 256, 0, st>>>(dst, src, n, scale);
+  return (int)hipGetLastError();
+}
+
 // nearest-2x upsample backward: the conv that read the upsampled map yields d(up) [B][2H][2W][C]; d(x)[y][x] = sum of its 2 x 2 block
 __global__ void __launch_bounds__(256) sumpool2x2_kernel(const half_t* __restrict__ dup, int B, int H, int W, int C, half_t* __restrict__ dx) {
   const int C8 = C >> 3;
@@ -303,20 +337,22 @@ int launch_zero_stuff2(const half_t* dy, int B, int Ho, int Wo, int C, half_t* o
 
 // Weight repack for dgrad through the forward kernel.  Forward layout: w[n][tap][c] (N x k*k x Cin, the igemm "weight rows").
 // dgrad of a stride-1, pad-(k/2) convolution is the same convolution of dy with wd[c][k*k - 1 - tap][n]; for k = 1 this is W^T.
-__global__ void __launch_bounds__(256) repack_dgrad_kernel(const half_t* __restrict__ w, int N, int taps, int Cin, half_t* __restrict__ wd) {
-  const size_t total = (size_t)N * taps * Cin;
+// Npad >= N: the gradient tensor's channel count (conv_out has 4 output channels; its gradient map is stored with 8): columns N .. Npad are 0.
+__global__ void __launch_bounds__(256) repack_dgrad_kernel(const half_t* __restrict__ w, int N, int Npad, int taps, int Cin, half_t* __restrict__ wd) {
+  const size_t total = (size_t)Npad * taps * Cin;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(idx % N);
-    size_t r = idx / N;
+    const int n = (int)(idx % Npad);
+    size_t r = idx / Npad;
     const int tp = (int)(r % taps);
     const int c = (int)(r / taps);
-    wd[idx] = w[((size_t)n * taps + (taps - 1 - tp)) * Cin + c];       // idx = (c * taps + tp) * N + n
+    wd[idx] = n < N ? w[((size_t)n * taps + (taps - 1 - tp)) * Cin + c] : (half_t)0.f;       // idx = (c * taps + tp) * Npad + n
   }
 }
-int launch_repack_dgrad(const half_t* w, int N, int taps, int Cin, half_t* wd, hipStream_t st) {
-  const size_t total = (size_t)N * taps * Cin;
+int launch_repack_dgrad(const half_t* w, int N, int Npad, int taps, int Cin, half_t* wd, hipStream_t st) {
+  if (Npad < N) return -3;
+  const size_t total = (size_t)Npad * taps * Cin;
   int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  repack_dgrad_kernel<<<blocks, 256, 0, st>>>(w, N, taps, Cin, wd);
+  repack_dgrad_kernel<<<blocks, 256, 0, st>>>(w, N, Npad, taps, Cin, wd);
   return (int)hipGetLastError();
 }
 
@@ -349,11 +385,11 @@ int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* d
 // NullInversion.null_optimization's inner iteration (inversion.py:209-218) around the UNet:
 //   eps = eps_u + w (eps_c - eps_u);  rec = c_x x + c_e eps  (prev_step with its two scalars folded by the caller);
 //   loss = mean((rec - target)^2);  d loss / d eps_u = (2 / n) (rec - target) c_e (1 - w).
-// One block: writes the gradient (fp16, times `grad_scale`: a power-of-two loss scale that the context-gradient GEMM removes) and the
+// One block: writes the gradient (fp32 in the layout of eps, times `grad_scale`: a power-of-two loss scale that the context-gradient GEMM removes) and the
 // loss (fp32 scalar) the host reads for the reference's early-stop test.
 __global__ void __launch_bounds__(1024) null_text_loss_kernel(const float* __restrict__ eps_u, const float* __restrict__ eps_c, const float* __restrict__ x,
                                                               const float* __restrict__ target, int n, float w, float c_x, float c_e,
-                                                              float grad_scale, half_t* __restrict__ d_eps_u, float* __restrict__ loss) {
+                                                              float grad_scale, float* __restrict__ d_eps_u, float* __restrict__ loss) {
   __shared__ float s_l[16];
   float acc = 0.f;
   const float k = 2.f / (float)n * c_e * (1.f - w) * grad_scale;
@@ -361,7 +397,7 @@ __global__ void __launch_bounds__(1024) null_text_loss_kernel(const float* __res
     const float e = eps_u[i] + w * (eps_c[i] - eps_u[i]);
     const float d = c_x * x[i] + c_e * e - target[i];
     acc += d * d;
-    d_eps_u[i] = (half_t)(k * d);
+    d_eps_u[i] = k * d;
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) s_l[threadIdx.x >> 6] = acc;
@@ -374,7 +410,7 @@ __global__ void __launch_bounds__(1024) null_text_loss_kernel(const float* __res
   }
 }
 int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x, float c_e,
-                          float grad_scale, half_t* d_eps_u, float* loss, hipStream_t st) {
+                          float grad_scale, float* d_eps_u, float* loss, hipStream_t st) {
   if (n <= 0) return -3;
   null_text_loss_kernel<<<1, 1024, 0, st>>>(eps_u, eps_c, x, target, n, w, c_x, c_e, grad_scale, d_eps_u, loss);
   return (int)hipGetLastError();

@@ -143,8 +143,10 @@ int launch_softmax_bwd_rows(const float* P, const float* dP, size_t R, int N, in
 int launch_accumulate_f16(half_t* dst, const half_t* src, size_t n, hipStream_t st);
 int launch_sumpool2x2(const half_t* dup, int B, int H, int W, int C, half_t* dx, hipStream_t st);
 int launch_zero_stuff2(const half_t* dy, int B, int Ho, int Wo, int C, half_t* out, hipStream_t st);
-int launch_repack_dgrad(const half_t* w, int N, int taps, int Cin, half_t* wd, hipStream_t st);
+int launch_repack_dgrad(const half_t* w, int N, int Npad, int taps, int Cin, half_t* wd, hipStream_t st);
+int launch_strided_add_f16(half_t* dst, const half_t* src, int ld, int off, size_t R, int C, int accumulate, hipStream_t st);
+int launch_add_f16_to_f32(float* dst, const half_t* src, size_t n, float scale, hipStream_t st);
 int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x, float c_e,
-                          float grad_scale, half_t* d_eps_u, float* loss, hipStream_t st);
+                          float grad_scale, float* d_eps_u, float* loss, hipStream_t st);
 int launch_adam_step(float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale, hipStream_t st);
 int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st);
