@@ -320,6 +320,12 @@ size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh);
  * [nsteps + 1][4*h*w] (x*_0 first), the "" and the source-prompt embeddings, the denoising timesteps; uncond_out [nsteps][77][768]
  * (the optimised embedding of every step), iters_out [nsteps] (nullable: Adam iterations run per step).  Context needs
  * max_unet_rows large enough for one row's activations kept without reuse (12 is). */
+/* pnpi_edit_loop with per-step unconditional embeddings uncond_steps [nsteps][nimg][77][768] (the output of pnpi_null_text_optimize):
+ * p2p_guidance_forward's `uncond_embeddings[i].expand(...)` (p2p_guidance_forward.py:56-57), or with uncond_first_only the single-branch
+ * variant (:92).  No direct-inversion offset, no reconstruction guidance (what the null-text method strings use). */
+int pnpi_edit_loop_uncond_steps(pnpi_ctx* ctx, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
+                                const int* timesteps_host, float guidance_scale, int prox, float quantile, const float* uncond_steps,
+                                int uncond_first_only, float* latents_out);
 int pnpi_unet_context_grad(pnpi_ctx* ctx, const float* latents, int t, const float* context, const float* d_eps, float* eps_out,
                            float* d_context_out);
 int pnpi_null_text_optimize(pnpi_ctx* ctx, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,

@@ -1942,9 +1942,12 @@ int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const flo
   return 0;
 }
 
-int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
-                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
-                   const pnpi_recon_desc* recon, float* latents_out) {
+// uncond_steps (nullable): [nsteps][nimg][77][768] per-step unconditional embeddings (null-text inversion).  p2p_guidance_forward uses the
+// step's embedding for every unconditional row of the image (p2p_guidance_forward.py:56-57); uncond_first_only = the single-branch variant
+// (:92: the first row only).  The text K / V are then projected once per STEP instead of once per loop.
+static int edit_loop_impl(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
+                          const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
+                          const pnpi_recon_desc* recon, float* latents_out, const float* uncond_steps, int uncond_first_only) {
   if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   const pnpi_model_config& g = c->cfg;
@@ -1966,12 +1969,28 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   CKP(upload_ints(c, inmap, &d_inmap));
   CK(launch_gather_rows_f32(x_T, d_expand, nimg * 2, E, lat, c->st));
   if (prox && !(quantile > 0.f)) CK(launch_fill_f32(thr, nimg, -quantile, c->st));   // negative quantile = fixed threshold (:43-44)
+  const size_t CE = (size_t)g.ctx_len * g.cross_dim;
+  float* ctx_step = nullptr;
+  if (uncond_steps) {
+    ctx_step = misc_f(c, (size_t)rows * CE);
+    CKH(hipMemcpyAsync(ctx_step, context4, (size_t)rows * CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  }
   LoopKV kv(c);
-  CKP(kv.begin(context4, rows));
+  if (!uncond_steps) CKP(kv.begin(context4, rows));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
+    const float* ctx_i = context4;
+    if (uncond_steps) {
+      for (int im = 0; im < nimg; ++im) {
+        const float* u = uncond_steps + ((size_t)i * nimg + im) * CE;
+        CKH(hipMemcpyAsync(ctx_step + (size_t)(4 * im) * CE, u, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+        if (!uncond_first_only) CKH(hipMemcpyAsync(ctx_step + (size_t)(4 * im + 1) * CE, u, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+      }
+      ctx_i = ctx_step;
+      CKP(kv.begin(ctx_i, rows));
+    }
     CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
-    int r = unet_fwd(c, in, rows, t, context4, use_ctrl, i, eps);
+    int r = unet_fwd(c, in, rows, t, ctx_i, use_ctrl, i, eps);
     if (r) return r;
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
@@ -1985,6 +2004,18 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
   if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
   return 0;
+}
+int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
+                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
+                   const pnpi_recon_desc* recon, float* latents_out) {
+  return edit_loop_impl(c, x_T, nimg, context4, noise_loss, offset_rows, ctrl_host, nsteps, ts, gs, prox, quantile, recon, latents_out, nullptr, 0);
+}
+int pnpi_edit_loop_uncond_steps(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
+                                const int* ts, float gs, int prox, float quantile, const float* uncond_steps, int uncond_first_only,
+                                float* latents_out) {
+  if (!uncond_steps) return PNPI_EINVAL;
+  return edit_loop_impl(c, x_T, nimg, context4, nullptr, 1, ctrl_host, nsteps, ts, gs, prox, quantile, nullptr, latents_out, uncond_steps,
+                        uncond_first_only);
 }
 
 /* offset_calculate + npass guidance-forward passes of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) advanced in
