@@ -283,6 +283,54 @@ int pnpi_op_groupnorm(pnpi_ctx* ctx, const void* x1, const void* x2, int C1, int
 int pnpi_op_layernorm(pnpi_ctx* ctx, const void* x, int M, int C, float eps, const float* gamma, const float* beta, void* out);
 int pnpi_op_geglu(pnpi_ctx* ctx, const void* x, int M, int inner, void* out);
 int pnpi_op_softmax_rows(pnpi_ctx* ctx, void* x, int M, int N, int ld);
+/* Activation-gradient kernels of the null-text / null-latent path (NullInversion.null_optimization's loss.backward(), inversion.py:
+ * 196-225) -- groundwork, kernel-level only (no method string reaches them yet).  fp16 tensors in the forward's layouts.
+ *   layernorm_bwd: dx of torch.nn.LayerNorm from the saved input;  groupnorm_bwd: dx (dense [B][HW][C1+C2]) of GroupNorm(+SiLU) over the
+ *   virtual concat (x1, x2);  geglu_bwd: d(projection) in the interleaved [x(32)|gate(32)] layout;  softmax_bwd_rows: dS = scale * P *
+ *   (dP - rowsum(dP * P)) as fp16 rows padded to ld;  accumulate: dst += src;  sumpool2x2: nearest-2x upsample backward;  zero_stuff2 +
+ *   repack_dgrad: stride-2 / stride-1 convolution dgrad through the forward kernel (wd[c][k*k-1-tap][n] = w[n][tap][c]);
+ *   null_text_loss: mse(prev_step(cfg(eps_u, eps_c)), target) and its gradient w.r.t. eps_u (times grad_scale);  adam_step: torch.optim.Adam
+ *   defaults, step k >= 1, gradient times inv_scale. */
+int pnpi_op_layernorm_bwd(pnpi_ctx* ctx, const void* x, const void* dy, int M, int C, float eps, const float* gamma, void* dx);
+int pnpi_op_groupnorm_bwd(pnpi_ctx* ctx, const void* x1, const void* x2, int C1, int C2, int B, int HW, int groups, float eps,
+                          const float* gamma, const float* beta, int silu, const void* dy, void* dx);
+int pnpi_op_geglu_bwd(pnpi_ctx* ctx, const void* h, const void* dy, int M, int inner, void* dh);
+int pnpi_op_softmax_bwd_rows(pnpi_ctx* ctx, const float* P, const float* dP, int R, int N, int ld, float scale, void* dS);
+int pnpi_op_accumulate(pnpi_ctx* ctx, void* dst, const void* src, size_t n);
+int pnpi_op_sumpool2x2(pnpi_ctx* ctx, const void* dup, int B, int H, int W, int C, void* dx);
+int pnpi_op_zero_stuff2(pnpi_ctx* ctx, const void* dy, int B, int Ho, int Wo, int C, void* out);
+int pnpi_op_repack_dgrad(pnpi_ctx* ctx, const void* w, int N, int taps, int Cin, void* wd);
+int pnpi_op_null_text_loss(pnpi_ctx* ctx, const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w,
+                           float c_x, float c_e, float grad_scale, void* d_eps_u, float* loss);
+int pnpi_op_adam_step(pnpi_ctx* ctx, float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale);
+/* Attention backward (CrossAttention.forward of my_diffusers/models/attention.py:217-259 differentiated), materialised per (row, head):
+ * q / k / v are [B*N][ld] fp16 views with head h at columns off + h * Dp (dh real columns, pad columns zero), d_o is [B*Nq][ldo] with
+ * heads * dh columns; dq / dk / dv receive the gradients in the layout of q / k / v (pad columns untouched).  scratch: device memory
+ * of at least pnpi_op_attention_bwd_scratch_bytes(Nq, Nk, dh) bytes. */
+int pnpi_op_attention_bwd(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* v, int ldv,
+                          int v_off, const void* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, void* dq,
+                          void* dk, void* dv, void* scratch, size_t scratch_bytes);
+size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh);
+
+/* ---- differentiable UNet forward (null-text path; groundwork) ---------------------------------------------------------------
+ * pnpi_unet_context_grad: eps = unet(latents [1][4][h][w], t, context [1][77][768]) with every activation recorded, then the reverse
+ * walk: d_context_out [77][768] = (d eps / d context)^T d_eps for the given d loss / d eps (fp32 in the layout of eps; multiply it by
+ * a power-of-two loss scale -- activation gradients travel in fp16 -- and divide d_context_out by it).  eps_out nullable.
+ * pnpi_null_text_optimize: NullInversion.null_optimization (models/p2p/inversion.py:196-225) for one image: ddim_latents
+ * [nsteps + 1][4*h*w] (x*_0 first), the "" and the source-prompt embeddings, the denoising timesteps; uncond_out [nsteps][77][768]
+ * (the optimised embedding of every step), iters_out [nsteps] (nullable: Adam iterations run per step).  Context needs
+ * max_unet_rows large enough for one row's activations kept without reuse (12 is). */
+/* pnpi_edit_loop with per-step unconditional embeddings uncond_steps [nsteps][nimg][77][768] (the output of pnpi_null_text_optimize):
+ * p2p_guidance_forward's `uncond_embeddings[i].expand(...)` (p2p_guidance_forward.py:56-57), or with uncond_first_only the single-branch
+ * variant (:92).  No direct-inversion offset, no reconstruction guidance (what the null-text method strings use). */
+int pnpi_edit_loop_uncond_steps(pnpi_ctx* ctx, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
+                                const int* timesteps_host, float guidance_scale, int prox, float quantile, const float* uncond_steps,
+                                int uncond_first_only, float* latents_out);
+int pnpi_unet_context_grad(pnpi_ctx* ctx, const float* latents, int t, const float* context, const float* d_eps, float* eps_out,
+                           float* d_context_out);
+int pnpi_null_text_optimize(pnpi_ctx* ctx, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,
+                            const int* timesteps_host, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out,
+                            int* iters_out_host);
 int pnpi_op_attention(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
                       int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
                       const int* rows_dev /*[nrows][4]*/, int nrows);

@@ -104,6 +104,21 @@ SYMBOLS = {
     "pnpi_op_layernorm": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "pnpi_op_geglu": (_i, [_vp, _vp, _i, _i, _vp]),
     "pnpi_op_softmax_rows": (_i, [_vp, _vp, _i, _i, _i]),
+    "pnpi_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "pnpi_op_groupnorm_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    "pnpi_op_geglu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "pnpi_op_softmax_bwd_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "pnpi_op_accumulate": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "pnpi_op_sumpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pnpi_op_zero_stuff2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pnpi_op_repack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pnpi_op_null_text_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp]),
+    "pnpi_op_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f]),
+    "pnpi_op_attention_bwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "pnpi_op_attention_bwd_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
+    "pnpi_edit_loop_uncond_steps": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, _i, _vp]),
+    "pnpi_unet_context_grad": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pnpi_null_text_optimize": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, C.POINTER(C.c_int)]),
     "pnpi_op_attention": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i]),
     "pnpi_op_cross_edit": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp,
                                 _vp, _vp, _vp, _i, _i]),

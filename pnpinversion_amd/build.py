@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libpnpi.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "step.hip", "api.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "step.hip", "bwd.hip", "api.hip"]
 HEADERS = ["common.h", "ops.h", "model.h", "tile_table.inc", os.path.join("..", "..", "include", "pnpi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-value"]
 # Per-file flags.  step.hip: the reference rounds every multiply / add separately (no FMA contraction).  attn.hip: keep the MFMA

@@ -321,6 +321,42 @@ static void prof_close(pnpi_ctx* c, ProfRec& r, int cls, double flops, double by
     }                                                         \
   } while (0)
 
+// ---------------------------------------------------------------------------------------------------- activation tape
+// A differentiable forward (NullInversion.null_optimization: loss.backward() w.r.t. the unconditional embedding, inversion.py:196-225)
+// records every op of the UNet forward below -- through the same wrappers the plain forward uses -- and keeps all activations (the
+// arenas stop releasing temporaries; one UNet row is ~0.4 GB).  tape_backward() walks the records in reverse.  Only activation
+// gradients exist (no weight gradients); the fused variants that would hide an intermediate are switched off while recording
+// (GEGLU in the GEMM epilogue, V^T written by the projection GEMM, the text K/V cache).
+enum { TK_CONV = 0, TK_GEMM = 1, TK_GN = 2, TK_LN = 3, TK_ATTN = 4, TK_GEGLU = 5, TK_TRANSPOSE_V = 6 };
+struct TapeOp {
+  int kind = 0;
+  const half_t *x1 = nullptr, *x2 = nullptr, *res = nullptr;
+  half_t* out = nullptr;
+  int C1 = 0, C2 = 0, B = 0, H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad = 0, ups = 0, N = 0;      // conv
+  const ConvW* cw = nullptr;
+  int lda = 0, M = 0, K = 0, ldw = 0, ldo = 0;                                                        // gemm
+  const half_t* w = nullptr;
+  float alpha = 1.f;
+  const NormW* nw = nullptr;                                                                         // norms
+  int G = 0, HW = 0, silu = 0;
+  float eps = 0.f;
+  const half_t *q = nullptr, *k = nullptr, *v = nullptr;                                             // attention (base tensors)
+  int ldq = 0, q_off = 0, ldk = 0, k_off = 0, ldv = 0, v_off = 0, heads = 0, Nq = 0, Nk = 0, Dp = 0, dh = 0;
+  float scale = 0.f;
+};
+struct Tape {
+  std::vector<TapeOp> ops;
+  bool rec = false;                                   // recording (forward in flight)
+  const half_t* no_grad_input = nullptr;              // the network input: its consumers' dgrad is skipped
+  const half_t* ctx16 = nullptr;                      // the text context of this forward: gradients into it are summed in fp32
+  Bump garena;                                        // gradient buffers + scratch of one backward
+  std::unordered_map<const void*, half_t*> grads;     // activation pointer -> gradient buffer (same shape)
+  std::unordered_map<const void*, half_t*> wd;        // weight pointer -> dgrad repack (device, built once)
+  float* d_ctx = nullptr;                             // [rows * ctx_len * cross_dim] fp32
+  void* attn_scratch = nullptr; size_t attn_scratch_bytes = 0;
+};
+static inline bool taping(pnpi_ctx* c) { return c->tape && c->tape->rec && !c->dry; }
+
 // ---------------------------------------------------------------------------------------------------- op wrappers
 // Per-channel GroupNorm partial sums attached to an activation by the GEMM that produced it ([tiles][C][2], `rows` per tile).
 struct Stats { const float* p = nullptr; int rows = 0; };
@@ -332,6 +368,10 @@ static half_t* palloc(pnpi_ctx* c, size_t n) { return (half_t*)c->persist.alloc(
 static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, const NormW& nw, int G, float eps,
                  int silu, half_t* out, Stats s1 = Stats(), Stats s2 = Stats()) {
   if (c->dry) return 0;
+  if (taping(c)) {
+    TapeOp o; o.kind = TK_GN; o.x1 = x1; o.x2 = x2; o.C1 = C1; o.C2 = C2; o.B = B; o.HW = HW; o.nw = &nw; o.G = G; o.eps = eps; o.silu = silu; o.out = out;
+    c->tape->ops.push_back(o);
+  }
   const bool ok1 = s1.p && s1.rows > 0 && HW % s1.rows == 0 && HW / s1.rows <= 256;
   const bool ok2 = !x2 || (s2.p && s2.rows > 0 && HW % s2.rows == 0 && HW / s2.rows <= 256);
   static const bool gn_nofuse = getenv("PNPI_GN_NOFUSE") != nullptr;   // ablation: always recompute the statistics
@@ -384,6 +424,11 @@ static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int 
   c->ctr.executed_gemm_flops += 2.0 * p.M * p.N * p.K;
   if (sr) { sr->buf = stats_alloc(c, p.M, p.N); sr->rows = 0; p.stats = sr->buf; }
   if (c->dry) return 0;
+  if (taping(c)) {
+    TapeOp o; o.kind = TK_CONV; o.x1 = x1; o.x2 = x2; o.C1 = C1p; o.C2 = C2; o.B = B; o.H = H; o.W = W; o.Ho = Ho; o.Wo = Wo; o.stride = stride; o.pad = pad;
+    o.ups = ups; o.N = p.N; o.cw = &w; o.res = res; o.out = out;
+    c->tape->ops.push_back(o);
+  }
   return igemm_prof(c, p, 2.0 * p.M * (double)w.cout * w.k * w.k * w.cin, sr);
 }
 
@@ -397,6 +442,10 @@ static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const ha
   if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
   c->ctr.executed_gemm_flops += 2.0 * M * N * K;
   if (c->dry) return 0;
+  if (taping(c) && out) {        // plain row-major outputs only: the recording forward uses no transposed / fused-GEGLU epilogue
+    TapeOp o; o.kind = TK_GEMM; o.x1 = a; o.lda = lda; o.M = M; o.K = K; o.w = w; o.ldw = ldw; o.N = N; o.res = res; o.out = out; o.ldo = ldo; o.alpha = alpha;
+    c->tape->ops.push_back(o);
+  }
   return igemm_prof(c, p, alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K);
 }
 
@@ -423,7 +472,7 @@ static int resnet_fwd(pnpi_ctx* c, const ResnetW& r, const half_t* x1, int C1, c
   }
   CK(op_conv(c, t3, r.cout, nullptr, 0, B, H, W, r.c2, 1, 1, 0, r.c2.b, sc, out, H, W, -1, nullptr, &q2));
   if (so) { so->p = q2.buf; so->rows = q2.rows; }
-  c->temp.release(mk);
+  if (!taping(c)) c->temp.release(mk);      // a recording forward keeps every activation for the backward pass
   return 0;
 }
 
@@ -569,6 +618,84 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   return 0;
 }
 
+// The same block while a tape is recording (null-text path: one prompt row, no controller): every intermediate the backward needs is
+// kept in its plain layout -- q | k | v as one row-major projection output (V^T for the flash kernel is a transposed COPY), the text
+// K / V projected inside the forward from the context (their gradient is the point of the exercise), GEGLU unfused.
+static int op_ln(pnpi_ctx* c, const half_t* x, int M, int C, const NormW& nw, half_t* out) {
+  if (c->dry) return 0;
+  if (taping(c)) { TapeOp o; o.kind = TK_LN; o.x1 = x; o.M = M; o.C1 = C; o.nw = &nw; o.eps = 1e-5f; o.out = out; c->tape->ops.push_back(o); }
+  PROF(PNPI_KC_LAYERNORM, 0.0, 2.0 * M * (double)C * 2.0, launch_layernorm(x, M, C, 1e-5f, nw.g, nw.b, out, c->st));
+  return 0;
+}
+static int transformer_fwd_tape(pnpi_ctx* c, const TransformerW& t, const half_t* x, int B, int H, int W, const half_t* ctx16, half_t* out) {
+  const pnpi_model_config& g = c->cfg;
+  c->tf_index++;
+  const int C = t.C, N = H * W, M = B * N, hd = t.heads * t.Dp, X = g.cross_dim, T = g.ctx_len;
+  const float scale = 1.0f / sqrtf((float)t.dh);
+  half_t* g0 = talloc(c, (size_t)M * C);
+  CK(op_gn(c, x, nullptr, C, 0, B, N, t.gn, g.norm_groups, 1e-6f, 0, g0));
+  half_t* hs = talloc(c, (size_t)M * C);
+  CK(op_conv(c, g0, C, nullptr, 0, B, H, W, t.proj_in, 1, 0, 0, t.proj_in.b, nullptr, hs, H, W));
+  // ---- self-attention
+  half_t* n1 = talloc(c, (size_t)M * C);
+  CK(op_ln(c, hs, M, C, t.ln1, n1));
+  half_t* qkv = talloc(c, (size_t)M * 3 * hd);
+  CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qkv, 3 * hd));
+  const int ldv = round_up_i(N, 8);
+  half_t* vt = talloc(c, (size_t)B * hd * ldv);
+  half_t* ao = talloc(c, (size_t)M * C);
+  if (!c->dry) {
+    for (int b = 0; b < B; ++b) CK(launch_transpose_f16(qkv + (size_t)b * N * 3 * hd + 2 * hd, 3 * hd, N, hd, vt + (size_t)b * hd * ldv, ldv, c->st));
+    AttnP a; a.q = qkv; a.ldq = 3 * hd; a.q_off = 0; a.k = qkv; a.ldk = 3 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv;
+    a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale; a.rows = c->cd.rows_id; a.nrows = B;
+    CK(launch_attn_flash(a, c->st));
+    if (taping(c)) {
+      TapeOp o; o.kind = TK_ATTN; o.q = qkv; o.ldq = 3 * hd; o.q_off = 0; o.k = qkv; o.ldk = 3 * hd; o.k_off = hd; o.v = qkv; o.ldv = 3 * hd; o.v_off = 2 * hd;
+      o.out = ao; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = N; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B;
+      c->tape->ops.push_back(o);
+    }
+  }
+  half_t* hs1 = talloc(c, (size_t)M * C);
+  CK(op_gemm(c, ao, C, M, C, t.o1.w, C, C, t.o1.b, hs, C, hs1, C));
+  // ---- cross-attention
+  half_t* n2 = talloc(c, (size_t)M * C);
+  CK(op_ln(c, hs1, M, C, t.ln2, n2));
+  half_t* q2 = talloc(c, (size_t)M * hd);
+  CK(op_gemm(c, n2, C, M, C, t.w_q2, C, hd, nullptr, nullptr, 0, q2, hd));
+  half_t* kv2 = talloc(c, (size_t)B * T * 2 * hd);
+  CK(op_gemm(c, ctx16, X, B * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, kv2, 2 * hd));
+  const int ldv2 = round_up_i(T, 8);
+  half_t* vt2 = talloc(c, (size_t)B * hd * ldv2);
+  half_t* ao2 = talloc(c, (size_t)M * C);
+  if (!c->dry) {
+    for (int b = 0; b < B; ++b) CK(launch_transpose_f16(kv2 + (size_t)b * T * 2 * hd + hd, 2 * hd, T, hd, vt2 + (size_t)b * hd * ldv2, ldv2, c->st));
+    AttnP a; a.q = q2; a.ldq = hd; a.q_off = 0; a.k = kv2; a.ldk = 2 * hd; a.k_off = 0; a.vt = vt2; a.ldv = ldv2;
+    a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale; a.rows = c->cd.rows_id; a.nrows = B;
+    CK(launch_attn_flash(a, c->st));
+    if (taping(c)) {
+      TapeOp o; o.kind = TK_ATTN; o.q = q2; o.ldq = hd; o.q_off = 0; o.k = kv2; o.ldk = 2 * hd; o.k_off = 0; o.v = kv2; o.ldv = 2 * hd; o.v_off = hd;
+      o.out = ao2; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = T; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B;
+      c->tape->ops.push_back(o);
+    }
+  }
+  half_t* hs2 = talloc(c, (size_t)M * C);
+  CK(op_gemm(c, ao2, C, M, C, t.o2.w, C, C, t.o2.b, hs1, C, hs2, C));
+  // ---- GEGLU feed-forward (unfused: the gate pre-activation is needed for its derivative)
+  half_t* n3 = talloc(c, (size_t)M * C);
+  CK(op_ln(c, hs2, M, C, t.ln3, n3));
+  half_t* f1 = talloc(c, (size_t)M * 8 * C);
+  CK(op_gemm(c, n3, C, M, C, t.ff1.w, C, 8 * C, t.ff1.b, nullptr, 0, f1, 8 * C));
+  half_t* f2 = talloc(c, (size_t)M * 4 * C);
+  if (!c->dry) {
+    CK(launch_geglu(f1, M, 4 * C, f2, c->st));
+    if (taping(c)) { TapeOp o; o.kind = TK_GEGLU; o.x1 = f1; o.out = f2; o.M = M; o.N = 4 * C; c->tape->ops.push_back(o); }
+  }
+  half_t* hs3 = talloc(c, (size_t)M * C);
+  CK(op_gemm(c, f2, 4 * C, M, 4 * C, t.ff2.w, 4 * C, C, t.ff2.b, hs2, C, hs3, C));
+  CK(op_conv(c, hs3, C, nullptr, 0, B, H, W, t.proj_out, 1, 0, 0, t.proj_out.b, x, out, H, W));
+  return 0;
+}
+
 // UNet2DConditionModel.forward (my_diffusers/models/unet_2d_condition.py:189-273)
 static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const float* context, bool use_ctrl, int cur_step,
                     float* eps_out) {
@@ -588,6 +715,7 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
   } else {
     ctx16 = palloc(c, (size_t)B * g.ctx_len * g.cross_dim);
   }
+  if (taping(c)) { c->tape->no_grad_input = x0; c->tape->ctx16 = ctx16; }
   if (!c->dry) {
     CK(launch_nchw_f32_to_nhwc_f16(latents, B, g.in_channels, S * S, 8, x0, c->st));
     if (ctx16) {
@@ -633,7 +761,8 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
       h = o; ch = oc; hs_ = ns;
       if (g.block_has_attn[i]) {
         half_t* o2 = palloc(c, (size_t)B * H * H * oc);
-        CKP(transformer_fwd(c, u.down_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
+        if (taping(c)) { CKP(transformer_fwd_tape(c, u.down_attn[i][j], h, B, H, H, ctx16, o2)); ns = Stats(); }
+        else CKP(transformer_fwd(c, u.down_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
         h = o2; hs_ = ns;
       }
       skips.push_back({h, ch, H, hs_});
@@ -652,7 +781,8 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
     Stats n1, n2, n3;
     CKP(resnet_fwd(c, u.mid_res[0], h, ch, nullptr, 0, B, H, H, G, eps, o, hs_, Stats(), &n1));
     half_t* o2 = palloc(c, (size_t)B * H * H * ch);
-    CKP(transformer_fwd(c, u.mid_attn, o, B, H, H, ctx16, use_ctrl, cur_step, o2, n1, &n2));
+    if (taping(c)) { CKP(transformer_fwd_tape(c, u.mid_attn, o, B, H, H, ctx16, o2)); n2 = Stats(); }
+    else CKP(transformer_fwd(c, u.mid_attn, o, B, H, H, ctx16, use_ctrl, cur_step, o2, n1, &n2));
     half_t* o3 = palloc(c, (size_t)B * H * H * ch);
     CKP(resnet_fwd(c, u.mid_res[1], o2, ch, nullptr, 0, B, H, H, G, eps, o3, n2, Stats(), &n3));
     h = o3; hs_ = n3;
@@ -667,7 +797,8 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
       h = o; ch = oc; hs_ = ns;
       if (g.block_has_attn[n - 1 - i]) {
         half_t* o2 = palloc(c, (size_t)B * H * H * oc);
-        CKP(transformer_fwd(c, u.up_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
+        if (taping(c)) { CKP(transformer_fwd_tape(c, u.up_attn[i][j], h, B, H, H, ctx16, o2)); ns = Stats(); }
+        else CKP(transformer_fwd(c, u.up_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
         h = o2; hs_ = ns;
       }
     }
@@ -690,6 +821,233 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
   c->ctr.unet_sample_forwards_cached_kv += (c->dry || !c->tkv.use) ? 0 : rows;
   if (c->persist.overflow || c->temp.overflow) return fail(c, PNPI_ENOMEM, "workspace overflow");
   return 0;
+}
+
+// Attention backward, materialised per (row, head) like the call-back path's forward (first version: generic GEMM launches and
+// transposes; a fused flash backward replaces it later).  q / k: [B*N][ld] views with the head's columns at off + h * Dp (pad columns
+// dh .. Dp are zero, as the forward guarantees); v: plain [B*Nk][ldvp] with the same head layout; d_o: [B*Nq][ldo], heads * dh wide.
+// Outputs dq / dk / dv in the layout of q / k / v (their pad columns are left untouched: clear the buffers first).
+//   S = scale q k^T, P = softmax(S);  dV = P^T dO;  dP = dO V^T;  dS = scale P (dP - rowsum(dP P));  dQ = dS K;  dK = dS^T Q.
+// scratch: Nq * Nk * 8 (S / P and dP, fp32) + 2 * Nq * ldp * 2 (P, dS as fp16) + 2 * Nk * ldq8 * 2 (their transposes) + dh * (ldp + 2 * ldq8) * 2
+// bytes (K^T, Q^T, dO^T), reused for every (row, head).
+static size_t attn_bwd_scratch_bytes(int Nq, int Nk, int dh) {
+  const size_t ldp = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
+  return align_up((size_t)Nq * Nk * 4, 256) * 2 + align_up((size_t)Nq * ldp * 2, 256) * 2 + align_up((size_t)Nk * ldq8 * 2, 256) * 2 +
+         align_up((size_t)dh * ldp * 2, 256) + align_up((size_t)dh * ldq8 * 2, 256) * 2;
+}
+static int attn_bwd_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp,
+                                 int v_off, const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B,
+                                 half_t* dq, half_t* dk, half_t* dv, void* scratch, size_t scratch_bytes) {
+  if (!scratch || scratch_bytes < attn_bwd_scratch_bytes(Nq, Nk, dh)) return fail(c, PNPI_ENOMEM, "attention backward scratch too small");
+  if ((dh & 7) || (ldq & 7) || (ldk & 7) || (ldvp & 7) || (ldo & 7)) return fail(c, PNPI_ESHAPE, "attention backward: extents must be multiples of 8");
+  const int ldp = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
+  char* sp = (char*)scratch;
+  auto take = [&](size_t bytes) { char* r = sp; sp += align_up(bytes, 256); return r; };
+  float* S = (float*)take((size_t)Nq * Nk * 4);
+  float* dP = (float*)take((size_t)Nq * Nk * 4);
+  half_t* P16 = (half_t*)take((size_t)Nq * ldp * 2);
+  half_t* dS16 = (half_t*)take((size_t)Nq * ldp * 2);
+  half_t* PT = (half_t*)take((size_t)Nk * ldq8 * 2);
+  half_t* dST = (half_t*)take((size_t)Nk * ldq8 * 2);
+  half_t* Kt = (half_t*)take((size_t)dh * ldp * 2);
+  half_t* Qt = (half_t*)take((size_t)dh * ldq8 * 2);
+  half_t* dOt = (half_t*)take((size_t)dh * ldq8 * 2);
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < heads; ++h) {
+      const half_t* qh = q + (size_t)b * Nq * ldq + q_off + h * Dp;
+      const half_t* kh = k + (size_t)b * Nk * ldk + k_off + h * Dp;
+      const half_t* vh = v + (size_t)b * Nk * ldvp + v_off + h * Dp;
+      const half_t* doh = d_o + (size_t)b * Nq * ldo + h * dh;
+      VtOut vs; vs.outT = S; vs.col0 = 0; vs.ld = Nk; vs.f32 = 1; vs.rpb = Nk;            // S[q][key] = scale * sum_d k[key][d] q[q][d]
+      CK(op_gemm(c, kh, ldk, Nk, dh, qh, ldq, Nq, nullptr, nullptr, 0, nullptr, Nq, scale, &vs));
+      CK(launch_softmax_rows_f32(S, (size_t)Nq, Nk, c->st));
+      VtOut vp; vp.outT = dP; vp.col0 = 0; vp.ld = Nk; vp.f32 = 1; vp.rpb = Nk;          // dP[q][key] = sum_d v[key][d] dO[q][d]
+      CK(op_gemm(c, vh, ldvp, Nk, dh, doh, ldo, Nq, nullptr, nullptr, 0, nullptr, Nq, 1.f, &vp));
+      CK(launch_f32_rows_to_f16_padded(S, (size_t)Nq, Nk, ldp, P16, c->st));
+      CK(launch_softmax_bwd_rows(S, dP, (size_t)Nq, Nk, ldp, scale, dS16, c->st));
+      CK(launch_transpose_f16(P16, ldp, Nq, Nk, PT, ldq8, c->st));
+      CK(launch_transpose_f16(dS16, ldp, Nq, Nk, dST, ldq8, c->st));
+      CK(launch_transpose_f16(kh, ldk, Nk, dh, Kt, ldp, c->st));
+      CK(launch_transpose_f16(qh, ldq, Nq, dh, Qt, ldq8, c->st));
+      CK(launch_transpose_f16(doh, ldo, Nq, dh, dOt, ldq8, c->st));
+      CK(op_gemm(c, dS16, ldp, Nq, ldp, Kt, ldp, dh, nullptr, nullptr, 0, dq + (size_t)b * Nq * ldq + q_off + h * Dp, ldq));        // dQ = dS K
+      CK(op_gemm(c, dST, ldq8, Nk, ldq8, Qt, ldq8, dh, nullptr, nullptr, 0, dk + (size_t)b * Nk * ldk + k_off + h * Dp, ldk));      // dK = dS^T Q
+      CK(op_gemm(c, PT, ldq8, Nk, ldq8, dOt, ldq8, dh, nullptr, nullptr, 0, dv + (size_t)b * Nk * ldvp + v_off + h * Dp, ldvp));    // dV = P^T dO
+    }
+  return 0;
+}
+// ---------------------------------------------------------------------------------------------------- tape backward
+static half_t* tape_galloc(pnpi_ctx* c, size_t n_halfs) {
+  Tape& T = *c->tape;
+  half_t* p = (half_t*)T.garena.alloc(n_halfs * sizeof(half_t));
+  return T.garena.overflow ? nullptr : p;
+}
+// dst = the gradient buffer of activation `key` (n halfs).  First contribution: allocated, `fresh` = true, the producer writes it
+// directly.  Later contributions: a scratch buffer is returned and tape_commit() adds it to the existing gradient.
+struct GradDst { half_t* p = nullptr; half_t* into = nullptr; bool fresh = false; };
+static int tape_target(pnpi_ctx* c, const void* key, size_t n, GradDst& d) {
+  Tape& T = *c->tape;
+  auto it = T.grads.find(key);
+  d.p = tape_galloc(c, n);
+  if (!d.p) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+  if (it == T.grads.end()) { T.grads[key] = d.p; d.fresh = true; d.into = d.p; }
+  else { d.fresh = false; d.into = it->second; }
+  return 0;
+}
+static int tape_commit(pnpi_ctx* c, const GradDst& d, size_t n) {
+  if (d.fresh) return 0;
+  CK(launch_accumulate_f16(d.into, d.p, n, c->st));
+  return 0;
+}
+// gradient of `key` += src[r * ld + off + 0 .. C) for r < R (dense destination [R][C])
+static int tape_add_strided(pnpi_ctx* c, const void* key, const half_t* src, int ld, int off, size_t R, int C) {
+  Tape& T = *c->tape;
+  auto it = T.grads.find(key);
+  if (it == T.grads.end()) {
+    half_t* p = tape_galloc(c, R * C);
+    if (!p) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+    T.grads[key] = p;
+    CK(launch_strided_add_f16(p, src, ld, off, R, C, 0, c->st));
+  } else {
+    CK(launch_strided_add_f16(it->second, src, ld, off, R, C, 1, c->st));
+  }
+  return 0;
+}
+// dgrad weights of a forward weight matrix w[N][taps][Cin] (built once per weight, kept on the device): wd[Cin][taps][Npad]
+static int tape_wd(pnpi_ctx* c, const half_t* w, int N, int Npad, int taps, int Cin, const half_t** out) {
+  Tape& T = *c->tape;
+  auto it = T.wd.find(w);
+  if (it == T.wd.end()) {
+    half_t* p = nullptr;
+    CKH(hipMalloc((void**)&p, (size_t)Cin * taps * Npad * sizeof(half_t)));
+    CK(launch_repack_dgrad(w, N, Npad, taps, Cin, p, c->st));
+    it = T.wd.emplace(w, p).first;
+  }
+  *out = it->second;
+  return 0;
+}
+static int raw_conv(pnpi_ctx* c, const half_t* x, int Cx, int B, int H, int W, int ks, int pad, const half_t* w, int Nout, half_t* out) {
+  GemmP p; gemm_defaults(p);
+  p.x1 = x; p.C1 = Cx; p.ldx1 = Cx; p.B = B; p.H = H; p.W = W; p.Ho = H; p.Wo = W; p.ksize = ks; p.stride = 1; p.pad = pad;
+  p.K = ks * ks * Cx; p.w = w; p.ldw = p.K; p.M = B * H * W; p.N = Nout; p.out = out; p.ldo = Nout;
+  return igemm_prof(c, p, 2.0 * p.M * (double)p.N * p.K);
+}
+
+// Reverse walk.  d_out: gradient of the network output as NHWC fp16 with 8 channels (channels 4 .. 7 zero), consumed by conv_out's record
+// (the one conv whose forward output is not an fp16 tensor).  Returns with T.d_ctx = d loss / d context (fp32, scaled like d_out).
+static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
+  Tape& T = *c->tape;
+  T.rec = false;
+  const pnpi_model_config& g = c->cfg;
+  for (size_t oi = T.ops.size(); oi-- > 0;) {
+    const TapeOp& o = T.ops[oi];
+    const half_t* dy = nullptr;
+    if (o.out) {
+      auto it = T.grads.find(o.out);
+      if (it == T.grads.end()) continue;          // nothing downstream depends on this op's output
+      dy = it->second;
+    } else if (o.kind == TK_CONV) {
+      dy = d_out;
+    } else continue;
+    switch (o.kind) {
+      case TK_CONV: {
+        const int taps = o.cw->k * o.cw->k, Cin = o.C1 + o.C2, Ng = o.out ? o.N : 8;
+        const size_t Mo = (size_t)o.B * o.Ho * o.Wo;
+        if (o.res) CKP(tape_add_strided(c, o.res, dy, Ng, 0, Mo, Ng));
+        if (o.x1 == T.no_grad_input) break;
+        const half_t* wd = nullptr;
+        CKP(tape_wd(c, o.cw->w, o.N, Ng, taps, Cin, &wd));
+        const half_t* src = dy;
+        int Hs = o.Ho, Ws = o.Wo;
+        if (o.stride == 2) {
+          half_t* z = tape_galloc(c, (size_t)o.B * 2 * o.Ho * 2 * o.Wo * Ng);
+          if (!z) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+          CK(launch_zero_stuff2(dy, o.B, o.Ho, o.Wo, Ng, z, c->st));
+          src = z; Hs = 2 * o.Ho; Ws = 2 * o.Wo;
+        }
+        half_t* dx = tape_galloc(c, (size_t)o.B * Hs * Ws * Cin);          // dense [B][Hs][Ws][C1 + C2]
+        if (!dx) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+        CK(raw_conv(c, src, Ng, o.B, Hs, Ws, o.cw->k, o.cw->k == 3 ? 1 : 0, wd, Cin, dx));
+        size_t Min = (size_t)o.B * Hs * Ws;
+        if (o.ups) {                                                         // the conv read the 2x-upsampled map
+          half_t* dd = tape_galloc(c, (size_t)o.B * o.H * o.W * Cin);
+          if (!dd) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+          CK(launch_sumpool2x2(dx, o.B, o.H, o.W, Cin, dd, c->st));
+          dx = dd; Min = (size_t)o.B * o.H * o.W;
+        }
+        CKP(tape_add_strided(c, o.x1, dx, Cin, 0, Min, o.C1));
+        if (o.C2) CKP(tape_add_strided(c, o.x2, dx, Cin, o.C1, Min, o.C2));
+        break;
+      }
+      case TK_GEMM: {
+        if (o.res) CKP(tape_add_strided(c, o.res, dy, o.ldo, 0, (size_t)o.M, o.N));
+        if (o.x1 == T.no_grad_input) break;
+        const half_t* wt = nullptr;
+        CKP(tape_wd(c, o.w, o.N, o.N, 1, o.K, &wt));                         // W^T: [K][N]
+        half_t* dx = tape_galloc(c, (size_t)o.M * o.K);
+        if (!dx) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+        CK(op_gemm(c, dy, o.ldo, o.M, o.N, wt, o.N, o.K, nullptr, nullptr, 0, dx, o.K, o.alpha));
+        if (o.x1 == T.ctx16) CK(launch_add_f16_to_f32(T.d_ctx, dx, (size_t)o.M * o.K, 1.f, c->st));
+        else CKP(tape_add_strided(c, o.x1, dx, o.K, 0, (size_t)o.M, o.K));
+        break;
+      }
+      case TK_GN: {
+        const int C = o.C1 + o.C2;
+        half_t* dx = tape_galloc(c, (size_t)o.B * o.HW * C);
+        if (!dx) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+        CK(launch_groupnorm_bwd(o.x1, o.x2, o.C1, o.C2, o.B, o.HW, o.G, o.eps, o.nw->g, o.nw->b, o.silu, dy, dx, c->st));
+        if (o.x1 != T.no_grad_input) CKP(tape_add_strided(c, o.x1, dx, C, 0, (size_t)o.B * o.HW, o.C1));
+        if (o.C2) CKP(tape_add_strided(c, o.x2, dx, C, o.C1, (size_t)o.B * o.HW, o.C2));
+        break;
+      }
+      case TK_LN: {
+        GradDst d;
+        CKP(tape_target(c, o.x1, (size_t)o.M * o.C1, d));
+        CK(launch_layernorm_bwd(o.x1, dy, o.M, o.C1, o.eps, o.nw->g, d.p, c->st));
+        CKP(tape_commit(c, d, (size_t)o.M * o.C1));
+        break;
+      }
+      case TK_GEGLU: {
+        GradDst d;
+        CKP(tape_target(c, o.x1, (size_t)o.M * 2 * o.N, d));
+        CK(launch_geglu_bwd(o.x1, dy, o.M, o.N, d.p, c->st));
+        CKP(tape_commit(c, d, (size_t)o.M * 2 * o.N));
+        break;
+      }
+      case TK_ATTN: {
+        const size_t need = attn_bwd_scratch_bytes(o.Nq, o.Nk, o.dh);
+        if (need > T.attn_scratch_bytes) {
+          if (T.attn_scratch) CKH(hipFree(T.attn_scratch));
+          T.attn_scratch = nullptr; T.attn_scratch_bytes = 0;
+          CKH(hipMalloc(&T.attn_scratch, need));
+          T.attn_scratch_bytes = need;
+        }
+        // q, k, v are column ranges of at most two projection outputs (self: one tensor; cross: q2 and kv2): their gradients are
+        // assembled in buffers of the projections' shapes, zero-initialised (the head pad columns get no gradient)
+        auto grad_of = [&](const half_t* base, size_t n, half_t** out) -> int {
+          auto it = T.grads.find(base);
+          if (it == T.grads.end()) {
+            half_t* p = tape_galloc(c, n);
+            if (!p) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+            CKH(hipMemsetAsync(p, 0, n * sizeof(half_t), c->st));
+            T.grads[base] = p; *out = p;
+          } else *out = it->second;
+          return 0;
+        };
+        half_t *gq = nullptr, *gk = nullptr, *gv = nullptr;
+        CKP(grad_of(o.q, (size_t)o.B * o.Nq * o.ldq, &gq));
+        CKP(grad_of(o.k, (size_t)o.B * o.Nk * o.ldk, &gk));
+        CKP(grad_of(o.v, (size_t)o.B * o.Nk * o.ldv, &gv));
+        // (the projection outputs have exactly one consumer each -- this attention -- so the kernels may overwrite, not accumulate)
+        CKP(attn_bwd_materialized(c, o.q, o.ldq, o.q_off, o.k, o.ldk, o.k_off, o.v, o.ldv, o.v_off, dy, o.ldo, o.heads, o.Nq, o.Nk, o.Dp, o.dh,
+                                  o.scale, o.B, gq, gk, gv, T.attn_scratch, T.attn_scratch_bytes));
+        break;
+      }
+      default: break;
+    }
+  }
+  (void)g;
+  return T.garena.overflow ? fail(c, PNPI_ENOMEM, "gradient arena overflow") : 0;
 }
 
 // AttentionBlock.forward (my_diffusers/models/attention.py:54-92): single head, scores materialised per image (VAE only)
@@ -1135,12 +1493,18 @@ void pnpi_destroy(pnpi_ctx* c) {
   void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial,
                   c->temb_table, c->temb_h, c->temb_emb, c->bias_scratch, c->bias_tab, c->tkv.base, c->rows_ident};
   for (void* b : bufs) (void)hipFree(b);
+  if (c->tape) {
+    (void)hipFree(c->tape->garena.base); (void)hipFree(c->tape->d_ctx); (void)hipFree(c->tape->attn_scratch);
+    for (auto& kv : c->tape->wd) (void)hipFree(kv.second);
+    delete c->tape;
+  }
   delete c;
 }
 
 static void invalidate_derived(pnpi_ctx* c) {     // caches of functions of the weights
   std::fill(c->bias_valid.begin(), c->bias_valid.end(), 0);
   c->tkv.rows = 0; c->tkv.use = false;
+  if (c->tape) { for (auto& kv : c->tape->wd) (void)hipFree(kv.second); c->tape->wd.clear(); }     // dgrad repacks of the old weights
 }
 
 int pnpi_load_weights(pnpi_ctx* c, const pnpi_named_tensor* ts, int n) {
@@ -1578,9 +1942,12 @@ int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const flo
   return 0;
 }
 
-int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
-                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
-                   const pnpi_recon_desc* recon, float* latents_out) {
+// uncond_steps (nullable): [nsteps][nimg][77][768] per-step unconditional embeddings (null-text inversion).  p2p_guidance_forward uses the
+// step's embedding for every unconditional row of the image (p2p_guidance_forward.py:56-57); uncond_first_only = the single-branch variant
+// (:92: the first row only).  The text K / V are then projected once per STEP instead of once per loop.
+static int edit_loop_impl(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
+                          const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
+                          const pnpi_recon_desc* recon, float* latents_out, const float* uncond_steps, int uncond_first_only) {
   if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   const pnpi_model_config& g = c->cfg;
@@ -1602,12 +1969,28 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   CKP(upload_ints(c, inmap, &d_inmap));
   CK(launch_gather_rows_f32(x_T, d_expand, nimg * 2, E, lat, c->st));
   if (prox && !(quantile > 0.f)) CK(launch_fill_f32(thr, nimg, -quantile, c->st));   // negative quantile = fixed threshold (:43-44)
+  const size_t CE = (size_t)g.ctx_len * g.cross_dim;
+  float* ctx_step = nullptr;
+  if (uncond_steps) {
+    ctx_step = misc_f(c, (size_t)rows * CE);
+    CKH(hipMemcpyAsync(ctx_step, context4, (size_t)rows * CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  }
   LoopKV kv(c);
-  CKP(kv.begin(context4, rows));
+  if (!uncond_steps) CKP(kv.begin(context4, rows));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
+    const float* ctx_i = context4;
+    if (uncond_steps) {
+      for (int im = 0; im < nimg; ++im) {
+        const float* u = uncond_steps + ((size_t)i * nimg + im) * CE;
+        CKH(hipMemcpyAsync(ctx_step + (size_t)(4 * im) * CE, u, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+        if (!uncond_first_only) CKH(hipMemcpyAsync(ctx_step + (size_t)(4 * im + 1) * CE, u, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+      }
+      ctx_i = ctx_step;
+      CKP(kv.begin(ctx_i, rows));
+    }
     CK(launch_gather_rows_f32(lat, d_inmap, rows, E, in, c->st));
-    int r = unet_fwd(c, in, rows, t, context4, use_ctrl, i, eps);
+    int r = unet_fwd(c, in, rows, t, ctx_i, use_ctrl, i, eps);
     if (r) return r;
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
@@ -1621,6 +2004,18 @@ int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
   if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
   return 0;
+}
+int pnpi_edit_loop(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const float* noise_loss, int offset_rows,
+                   const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
+                   const pnpi_recon_desc* recon, float* latents_out) {
+  return edit_loop_impl(c, x_T, nimg, context4, noise_loss, offset_rows, ctrl_host, nsteps, ts, gs, prox, quantile, recon, latents_out, nullptr, 0);
+}
+int pnpi_edit_loop_uncond_steps(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
+                                const int* ts, float gs, int prox, float quantile, const float* uncond_steps, int uncond_first_only,
+                                float* latents_out) {
+  if (!uncond_steps) return PNPI_EINVAL;
+  return edit_loop_impl(c, x_T, nimg, context4, nullptr, 1, ctrl_host, nsteps, ts, gs, prox, quantile, nullptr, latents_out, uncond_steps,
+                        uncond_first_only);
 }
 
 /* offset_calculate + npass guidance-forward passes of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) advanced in
@@ -1808,6 +2203,168 @@ int pnpi_op_geglu(pnpi_ctx* c, const void* x, int M, int inner, void* out) {
 }
 int pnpi_op_softmax_rows(pnpi_ctx* c, void* x, int M, int N, int ld) {
   CK(launch_softmax_rows((half_t*)x, M, N, ld, c->st));
+  return 0;
+}
+// ---- differentiable UNet forward (null-text path groundwork)
+static int tape_ensure(pnpi_ctx* c) {
+  if (c->tape) return 0;
+  Tape* T = new Tape();
+  const pnpi_model_config& g = c->cfg;
+  T->garena.cap = (size_t)2560 << 20;                    // gradients + dgrad scratch of one UNet row (SD-1.x: ~1.1 GB)
+  CKH(hipMalloc((void**)&T->garena.base, T->garena.cap));
+  CKH(hipMalloc((void**)&T->d_ctx, (size_t)g.ctx_len * g.cross_dim * sizeof(float)));
+  c->tape = T;
+  return 0;
+}
+// eps = UNet(latents, t, context) for ONE row, and d_context = (d loss / d eps)^T (d eps / d context) for the given d loss / d eps
+// (fp32, the layout of eps; pre-multiplied by the caller's power-of-two loss scale -- activations' gradients travel in fp16).
+int pnpi_unet_context_grad(pnpi_ctx* c, const float* latents, int t, const float* context, const float* d_eps, float* eps_out, float* d_context_out) {
+  if (!c || !latents || !context || !d_eps || !d_context_out) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  CKP(tape_ensure(c));
+  Tape& T = *c->tape;
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  float* eps = eps_out ? eps_out : misc_f(c, E);
+  T.ops.clear(); T.grads.clear(); T.garena.reset(); T.garena.overflow = false;
+  c->tkv.use = false;
+  T.rec = true;
+  int r = unet_fwd(c, latents, 1, t, context, false, 0, eps);
+  T.rec = false;
+  if (r) return r;
+  half_t* d_out = tape_galloc(c, (size_t)g.sample_size * g.sample_size * 8);
+  if (!d_out) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+  CK(launch_nchw_f32_to_nhwc_f16(d_eps, 1, g.in_channels, g.sample_size * g.sample_size, 8, d_out, c->st));
+  CKH(hipMemsetAsync(T.d_ctx, 0, CE * sizeof(float), c->st));
+  CKP(tape_backward(c, d_out));
+  CKH(hipMemcpyAsync(d_context_out, T.d_ctx, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  return 0;
+}
+
+// NullInversion.null_optimization (models/p2p/inversion.py:196-225) for one image, device resident.  ddim_latents [nsteps + 1][E] (the
+// inversion trajectory, x*_0 first), ctx_uncond / ctx_cond [77][768]; uncond_out [nsteps][77][768] receives the optimised embedding of
+// every step.  Per step: eps_c once; up to num_inner_steps x (recording forward with the current embedding, loss + gradient, backward to
+// the embedding, Adam); the loss is read back for the reference's early-stop test; then the CFG step with the optimised embedding.
+int pnpi_null_text_optimize(pnpi_ctx* c, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,
+                            const int* ts, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out, int* iters_out) {
+  if (!c || !ddim_latents || !ctx_uncond || !ctx_cond || !ts || !uncond_out || nsteps <= 0 || num_inner_steps < 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  CKP(tape_ensure(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  const int ratio = g.n_train_timesteps / nsteps;
+  const float scale = 4096.f;                                   // loss scale of the fp16 activation gradients (removed before Adam)
+  CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  float* eps2 = misc_f(c, 2 * E);                               // [eps_u | eps_c]
+  float* d_eps = misc_f(c, E);
+  float* lat = misc_f(c, E);
+  float* unc = misc_f(c, CE);
+  float* am = misc_f(c, CE);
+  float* av = misc_f(c, CE);
+  float* gctx = misc_f(c, CE);
+  float* loss_d = misc_f(c, 1);
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  CKH(hipMemcpyAsync(unc, ctx_uncond, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  CKH(hipMemcpyAsync(lat, ddim_latents + (size_t)nsteps * E, E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[i];
+    float a_t, a_p; CKP(alphas_for(c, t, ratio, false, &a_t, &a_p));
+    const double sa_t = sqrt((double)a_t), sb_t = sqrt(1.0 - a_t), sa_p = sqrt((double)a_p), sb_p = sqrt(1.0 - a_p);
+    const float c_x = (float)(sa_p / sa_t), c_e = (float)(sb_p - sa_p * sb_t / sa_t);       // rec = c_x x + c_e eps
+    const float* target = ddim_latents + (size_t)(nsteps - i - 1) * E;
+    int its = 0;
+    if (num_inner_steps > 0) {
+      const float lr = (float)(1e-2 * (1.0 - i / 100.0));
+      c->tkv.use = false;
+      int r = unet_fwd(c, lat, 1, t, ctx_cond, false, 0, eps2 + E);
+      if (r) return r;
+      CKH(hipMemsetAsync(am, 0, CE * sizeof(float), c->st));
+      CKH(hipMemsetAsync(av, 0, CE * sizeof(float), c->st));
+      for (int j = 0; j < num_inner_steps; ++j) {
+        // forward with the tape recording; the loss head needs eps_u first, so forward and backward are two calls of the tape machinery
+        Tape& T = *c->tape;
+        T.ops.clear(); T.grads.clear(); T.garena.reset(); T.garena.overflow = false;
+        T.rec = true;
+        r = unet_fwd(c, lat, 1, t, unc, false, 0, eps2);
+        T.rec = false;
+        if (r) return r;
+        CK(launch_null_text_loss(eps2, eps2 + E, lat, target, (int)E, guidance_scale, c_x, c_e, scale, d_eps, loss_d, c->st));
+        half_t* d_out = tape_galloc(c, (size_t)g.sample_size * g.sample_size * 8);
+        if (!d_out) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+        CK(launch_nchw_f32_to_nhwc_f16(d_eps, 1, g.in_channels, g.sample_size * g.sample_size, 8, d_out, c->st));
+        CKH(hipMemsetAsync(T.d_ctx, 0, CE * sizeof(float), c->st));
+        CKP(tape_backward(c, d_out));
+        CK(launch_adam_step(unc, am, av, T.d_ctx, (int)CE, j + 1, lr, 1.f / scale, c->st));
+        float loss_h = 0.f;
+        CKH(hipMemcpyAsync(&loss_h, loss_d, sizeof(float), hipMemcpyDeviceToHost, c->st));
+        CKH(hipStreamSynchronize(c->st));
+        its = j + 1;
+        if (loss_h < epsilon + i * 2e-5f) break;
+      }
+    }
+    if (iters_out) iters_out[i] = its;
+    CKH(hipMemcpyAsync(uncond_out + (size_t)i * CE, unc, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
+    // latent_cur = prev_step(CFG(eps(unc), eps(cond)))   (get_noise_pred with the optimised embedding, inversion.py:221-224)
+    c->tkv.use = false;
+    int r = unet_fwd(c, lat, 1, t, unc, false, 0, eps2);
+    if (r) return r;
+    if (num_inner_steps == 0) { r = unet_fwd(c, lat, 1, t, ctx_cond, false, 0, eps2 + E); if (r) return r; }
+    CK(launch_cfg_ddim_prev(eps2, lat, 1, 1, E, guidance_scale, a_t, a_p, nullptr, 0, nullptr, 1.f, nullptr, lat, c->st));
+  }
+  return 0;
+}
+
+int pnpi_op_attention_bwd(pnpi_ctx* c, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* v, int ldv, int v_off,
+                          const void* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, void* dq, void* dk, void* dv,
+                          void* scratch, size_t scratch_bytes) {
+  if (!c || !q || !k || !v || !d_o || !dq || !dk || !dv) return PNPI_EINVAL;
+  CKP(attn_bwd_materialized(c, (const half_t*)q, ldq, q_off, (const half_t*)k, ldk, k_off, (const half_t*)v, ldv, v_off, (const half_t*)d_o, ldo,
+                            heads, Nq, Nk, Dp, dh, scale, B, (half_t*)dq, (half_t*)dk, (half_t*)dv, scratch, scratch_bytes));
+  return 0;
+}
+size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh) { return attn_bwd_scratch_bytes(Nq, Nk, dh); }
+// ---- activation-gradient kernels (null-text path groundwork; tests/test_gpu_backward.py)
+int pnpi_op_layernorm_bwd(pnpi_ctx* c, const void* x, const void* dy, int M, int C, float eps, const float* gamma, void* dx) {
+  CK(launch_layernorm_bwd((const half_t*)x, (const half_t*)dy, M, C, eps, gamma, (half_t*)dx, c->st));
+  return 0;
+}
+int pnpi_op_groupnorm_bwd(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                          const float* beta, int silu, const void* dy, void* dx) {
+  CK(launch_groupnorm_bwd((const half_t*)x1, (const half_t*)x2, C1, C2, B, HW, G, eps, gamma, beta, silu, (const half_t*)dy, (half_t*)dx, c->st));
+  return 0;
+}
+int pnpi_op_geglu_bwd(pnpi_ctx* c, const void* h, const void* dy, int M, int inner, void* dh) {
+  CK(launch_geglu_bwd((const half_t*)h, (const half_t*)dy, M, inner, (half_t*)dh, c->st));
+  return 0;
+}
+int pnpi_op_softmax_bwd_rows(pnpi_ctx* c, const float* P, const float* dP, int R, int N, int ld, float scale, void* dS) {
+  CK(launch_softmax_bwd_rows(P, dP, (size_t)R, N, ld, scale, (half_t*)dS, c->st));
+  return 0;
+}
+int pnpi_op_accumulate(pnpi_ctx* c, void* dst, const void* src, size_t n) {
+  CK(launch_accumulate_f16((half_t*)dst, (const half_t*)src, n, c->st));
+  return 0;
+}
+int pnpi_op_sumpool2x2(pnpi_ctx* c, const void* dup, int B, int H, int W, int C, void* dx) {
+  CK(launch_sumpool2x2((const half_t*)dup, B, H, W, C, (half_t*)dx, c->st));
+  return 0;
+}
+int pnpi_op_zero_stuff2(pnpi_ctx* c, const void* dy, int B, int Ho, int Wo, int C, void* out) {
+  CK(launch_zero_stuff2((const half_t*)dy, B, Ho, Wo, C, (half_t*)out, c->st));
+  return 0;
+}
+int pnpi_op_repack_dgrad(pnpi_ctx* c, const void* w, int N, int taps, int Cin, void* wd) {
+  CK(launch_repack_dgrad((const half_t*)w, N, N, taps, Cin, (half_t*)wd, c->st));
+  return 0;
+}
+int pnpi_op_null_text_loss(pnpi_ctx* c, const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x,
+                           float c_e, float grad_scale, void* d_eps_u, float* loss) {
+  CK(launch_null_text_loss(eps_u, eps_c, x, target, n, w, c_x, c_e, grad_scale, (float*)d_eps_u, loss, c->st));
+  return 0;
+}
+int pnpi_op_adam_step(pnpi_ctx* c, float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale) {
+  CK(launch_adam_step(p, m, v, g, n, k, lr, inv_scale, c->st));
   return 0;
 }
 int pnpi_op_attention(pnpi_ctx* c, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt, int ldv,

@@ -1,0 +1,437 @@
+// Activation-gradient ("dgrad only") kernels for the null-text / null-latent inversion path (NullInversion.null_optimization,
+// models/p2p/inversion.py:196-225: loss.backward() through the UNet w.r.t. the 77 x 768 unconditional embedding).
+// Everything here runs at ONE UNet row (the reference optimises one embedding at a time), so the tensors are <= 2.6 MB and L2 /
+// Infinity-Cache resident: the kernels are written for few launches and short dependency chains, not for HBM streaming.
+// Conv / linear dgrad is not here: it is the forward igemm kernel on repacked weights (repack_dgrad_kernel below).
+#include <algorithm>
+#include "ops.h"
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// y = (x - mean) * rstd * gamma + beta  (torch.nn.LayerNorm, eps inside the sqrt).  With g = dy * gamma and xhat = (x - mean) rstd:
+//   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)).
+// One wavefront per row, the row in registers (C <= 2048), statistics recomputed from x exactly as the forward does.
+template <int VPL>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int M, int C, float eps,
+                                                            const float* __restrict__ gamma, half_t* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C8 = C >> 3;
+  half8 xv[VPL], gv[VPL];
+  bool ok[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ok[i] = lane + 64 * i < C8;
+    const int cv = min(lane + 64 * i, C8 - 1);
+    xv[i] = ldg_half8(x + (size_t)row * C + cv * 8);
+    gv[i] = ldg_half8(dy + (size_t)row * C + cv * 8);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+    if (ok[i]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)xv[i][j];
+    }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+    if (ok[i]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)xv[i][j] - mean; q += d * d; }
+    }
+  q = wave_sum(q);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  float g[VPL][8];
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c0 = min(lane + 64 * i, C8 - 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      g[i][j] = ok[i] ? (float)gv[i][j] * gamma[c0 + j] : 0.f;
+      const float xh = ((float)xv[i][j] - mean) * rstd;
+      a += g[i][j];
+      b += ok[i] ? g[i][j] * xh : 0.f;
+    }
+  }
+  a = wave_sum(a) / (float)C;
+  b = wave_sum(b) / (float)C;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (!ok[i]) continue;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = ((float)xv[i][j] - mean) * rstd;
+      o[j] = (half_t)(rstd * (g[i][j] - a - xh * b));
+    }
+    *reinterpret_cast<half8*>(dx + (size_t)row * C + (lane + 64 * i) * 8) = o;
+  }
+}
+
+int launch_layernorm_bwd(const half_t* x, const half_t* dy, int M, int C, float eps, const float* gamma, half_t* dx, hipStream_t st) {
+  if ((C & 7) || C > 2048 || M <= 0) return -3;
+  const int C8 = C >> 3;
+  if (C8 <= 64) layernorm_bwd_kernel<1><<<(M + 3) / 4, 256, 0, st>>>(x, dy, M, C, eps, gamma, dx);
+  else if (C8 <= 128) layernorm_bwd_kernel<2><<<(M + 3) / 4, 256, 0, st>>>(x, dy, M, C, eps, gamma, dx);
+  else layernorm_bwd_kernel<4><<<(M + 3) / 4, 256, 0, st>>>(x, dy, M, C, eps, gamma, dx);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm (+ SiLU) backward
+// Forward (norm.hip): z = (x - mean_g) * rstd_g * gamma_c + beta_c over the (HW x cpg) slice of (sample, group); y = silu ? z sigma(z) : z.
+// Backward: dz = dy * (silu ? sigma(z) (1 + z (1 - sigma(z))) : 1);  h = dz * gamma;  with n = HW * cpg and xhat = (x - mean) rstd:
+//   dx = rstd * (h - sum(h) / n - xhat * sum(h * xhat) / n).
+// One 1024-thread block per (sample, group), three sweeps over the slice (statistics; the two sums; the result) -- the slice is at most
+// 4096 x 80 halfs and cache resident.  x may be the virtual concat of two tensors (x1: C1 channels, x2: C2), as in the forward; the
+// gradient is written densely as [B][HW][C1 + C2] (the consumers read it back as two strided views).
+__global__ void __launch_bounds__(1024) groupnorm_bwd_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1, int C2, int HW,
+                                                             int G, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int silu, const half_t* __restrict__ dy, half_t* __restrict__ dx) {
+  __shared__ float s_a[16], s_b[16];
+  const int C = C1 + C2, cpg = C / G;
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int n = HW * cpg;
+  auto xat = [&](int pix, int c) -> float {
+    const bool first = c < C1;
+    const half_t* sb = first ? x1 : x2;
+    const int ld = first ? C1 : C2, cc = first ? c : c - C1;
+    return (float)sb[((size_t)b * HW + pix) * ld + cc];
+  };
+  auto block_sum2 = [&](float& u, float& v) {
+    u = wave_sum(u); v = wave_sum(v);
+    __syncthreads();                                      // s_a / s_b may still be read from the previous reduction
+    if ((tid & 63) == 0) { s_a[tid >> 6] = u; s_b[tid >> 6] = v; }
+    __syncthreads();
+    u = 0.f; v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { u += s_a[w]; v += s_b[w]; }
+  };
+  float s = 0.f, q = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    const int pix = i / cpg, c = g * cpg + (i - pix * cpg);
+    const float f = xat(pix, c);
+    s += f; q += f * f;
+  }
+  block_sum2(s, q);
+  const float mean = s / (float)n;
+  float var = q / (float)n - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  auto hval = [&](int pix, int c, float& xh) -> float {
+    xh = (xat(pix, c) - mean) * rstd;
+    float d = (float)dy[((size_t)b * HW + pix) * C + c];
+    if (silu) {
+      const float z = xh * gamma[c] + beta[c];
+      const float sg = 1.f / (1.f + __expf(-z));
+      d *= sg * (1.f + z * (1.f - sg));
+    }
+    return d * gamma[c];
+  };
+  float sh = 0.f, shx = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    const int pix = i / cpg, c = g * cpg + (i - pix * cpg);
+    float xh;
+    const float h = hval(pix, c, xh);
+    sh += h; shx += h * xh;
+  }
+  block_sum2(sh, shx);
+  const float ma = sh / (float)n, mb = shx / (float)n;
+  for (int i = tid; i < n; i += 1024) {
+    const int pix = i / cpg, c = g * cpg + (i - pix * cpg);
+    float xh;
+    const float h = hval(pix, c, xh);
+    dx[((size_t)b * HW + pix) * C + c] = (half_t)(rstd * (h - ma - xh * mb));
+  }
+}
+
+int launch_groupnorm_bwd(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                         const float* beta, int silu, const half_t* dy, half_t* dx, hipStream_t st) {
+  const int C = C1 + C2;
+  if (C % G || B <= 0 || HW <= 0 || (C2 && !x2)) return -3;
+  groupnorm_bwd_kernel<<<dim3(B, G), 1024, 0, st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, dy, dx);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU backward
+// Forward (norm.hip geglu_kernel / the fused GEMM epilogue): out[m][c] = a * gelu(gt), a = h[m][xc], gt = h[m][xc + 32] with the
+// projection's columns interleaved in [x(32) | gate(32)] groups: xc = (c >> 5) * 64 + (c & 31).
+// Backward into the same interleaved layout: d a = dy * gelu(gt);  d gt = dy * a * (Phi(gt) + gt phi(gt)).
+__device__ __forceinline__ void gelu_and_grad(float x, float& gelu, float& dgelu) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);     // exp(-x^2 / 2)
+  const float half_erfc = 0.5f * p * t * e;
+  const float Phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  gelu = x * Phi;
+  dgelu = Phi + x * 0.39894228040143267794f * e;                                // + x * phi(x)
+}
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const half_t* __restrict__ h, const half_t* __restrict__ dy, int M, int I,
+                                                        half_t* __restrict__ dh) {
+  const int I8 = I >> 3;
+  const size_t total = (size_t)M * I8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = idx / I8;
+    const int c = (int)(idx - m * I8) * 8;
+    const int xc = (c >> 5) * 64 + (c & 31);
+    const half8 a = ldg_half8(h + m * 2 * I + xc), gt = ldg_half8(h + m * 2 * I + xc + 32), d = ldg_half8(dy + m * I + c);
+    half8 da, dg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float ge, dge;
+      gelu_and_grad((float)gt[j], ge, dge);
+      da[j] = (half_t)((float)d[j] * ge);
+      dg[j] = (half_t)((float)d[j] * (float)a[j] * dge);
+    }
+    *reinterpret_cast<half8*>(dh + m * 2 * I + xc) = da;
+    *reinterpret_cast<half8*>(dh + m * 2 * I + xc + 32) = dg;
+  }
+}
+int launch_geglu_bwd(const half_t* h, const half_t* dy, int M, int I, half_t* dh, hipStream_t st) {
+  if (I & 31) return -3;
+  const size_t total = (size_t)M * (I >> 3);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  geglu_bwd_kernel<<<blocks, 256, 0, st>>>(h, dy, M, I, dh);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ softmax backward (materialised attention)
+// P = softmax(S) row-wise (fp32 [R][N]);  dS = P * (dP - sum_j dP_j P_j).  The result feeds two GEMMs (dQ = dS K, dK = dS^T Q), so it
+// is written as fp16 with rows padded to `ld` (zeros), like f32_rows_to_f16_padded.  One wavefront per row.
+__global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const float* __restrict__ P, const float* __restrict__ dP, size_t R, int N, int ld,
+                                                               float scale, half_t* __restrict__ dS) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* p = P + row * N;
+  const float* d = dP + row * N;
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += p[c] * d[c];
+  s = wave_sum(s);
+  half_t* o = dS + row * ld;
+  for (int c = lane; c < ld; c += 64) o[c] = c < N ? (half_t)(scale * p[c] * (d[c] - s)) : (half_t)0.f;
+}
+int launch_softmax_bwd_rows(const float* P, const float* dP, size_t R, int N, int ld, float scale, half_t* dS, hipStream_t st) {
+  if (ld < N || R == 0) return -3;
+  softmax_bwd_rows_kernel<<<(unsigned)((R + 3) / 4), 256, 0, st>>>(P, dP, R, N, ld, scale, dS);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ small tensor ops of the tape walk
+// dst += src (gradient accumulation where a tensor has two consumers: residual / skip connections), fp32 sum, one rounding
+__global__ void __launch_bounds__(256) accumulate_f16_kernel(half_t* __restrict__ dst, const half_t* __restrict__ src, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    half8 a = ldg_half8(dst + i * 8);
+    const half8 b = ldg_half8(src + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (half_t)((float)a[j] + (float)b[j]);
+    *reinterpret_cast<half8*>(dst + i * 8) = a;
+  }
+}
+int launch_accumulate_f16(half_t* dst, const half_t* src, size_t n, hipStream_t st) {
+  if (n & 7) return -3;
+  const size_t n8 = n >> 3;
+  int blocks = (int)std::min<size_t>((n8 + 255) / 256, 2048);
+  accumulate_f16_kernel<<<blocks, 256, 0, st>>>(dst, src, n8);
+  return (int)hipGetLastError();
+}
+
+// dst[r][0 .. C) (+)= src[r * ld + off + 0 .. C): the two halves of a dense concat gradient go back to the two source tensors
+__global__ void __launch_bounds__(256) strided_add_f16_kernel(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld, int off, size_t R, int C,
+                                                              int accumulate) {
+  const int C8 = C >> 3;
+  const size_t total = R * C8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = idx / C8;
+    const int cv = (int)(idx - r * C8);
+    half8 v = ldg_half8(src + r * ld + off + cv * 8);
+    if (accumulate) {
+      const half8 a = ldg_half8(dst + r * C + cv * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)a[j] + (float)v[j]);
+    }
+    *reinterpret_cast<half8*>(dst + r * C + cv * 8) = v;
+  }
+}
+int launch_strided_add_f16(half_t* dst, const half_t* src, int ld, int off, size_t R, int C, int accumulate, hipStream_t st) {
+  if ((C & 7) || (ld & 7) || (off & 7)) return -3;
+  const size_t total = R * (C >> 3);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  strided_add_f16_kernel<<<blocks, 256, 0, st>>>(dst, src, ld, off, R, C, accumulate);
+  return (int)hipGetLastError();
+}
+// dst (fp32) += scale * src (fp16): the context gradient is summed over the 16 cross-attention layers in fp32
+__global__ void __launch_bounds__(256) add_f16_to_f32_kernel(float* __restrict__ dst, const half_t* __restrict__ src, size_t n, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += scale * (float)src[i];
+}
+int launch_add_f16_to_f32(float* dst, const half_t* src, size_t n, float scale, hipStream_t st) {
+  int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+  add_f16_to_f32_kernel<<<blocks, 256, 0, st>>>(dst, src, n, scale);
+  return (int)hipGetLastError();
+}
+
+// nearest-2x upsample backward: the conv that read the upsampled map yields d(up) [B][2H][2W][C]; d(x)[y][x] = sum of its 2 x 2 block
+__global__ void __launch_bounds__(256) sumpool2x2_kernel(const half_t* __restrict__ dup, int B, int H, int W, int C, half_t* __restrict__ dx) {
+  const int C8 = C >> 3;
+  const size_t total = (size_t)B * H * W * C8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % C8);
+    size_t r = idx / C8;
+    const int xo = (int)(r % W); r /= W;
+    const int yo = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        const half8 v = ldg_half8(dup + (((size_t)b * 2 * H + 2 * yo + dy) * 2 * W + 2 * xo + dxx) * C + cv * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+      }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+    *reinterpret_cast<half8*>(dx + (((size_t)b * H + yo) * W + xo) * C + cv * 8) = o;
+  }
+}
+int launch_sumpool2x2(const half_t* dup, int B, int H, int W, int C, half_t* dx, hipStream_t st) {
+  if (C & 7) return -3;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  sumpool2x2_kernel<<<blocks, 256, 0, st>>>(dup, B, H, W, C, dx);
+  return (int)hipGetLastError();
+}
+
+// stride-2 convolution backward, first half: dy [B][Ho][Wo][C] scattered to the even positions of a zero map [B][2Ho][2Wo][C]; the
+// stride-1 convolution with the flipped / transposed weights over it (igemm kernel, pad chosen by the caller) completes the dgrad.
+__global__ void __launch_bounds__(256) zero_stuff2_kernel(const half_t* __restrict__ dy, int B, int Ho, int Wo, int C, half_t* __restrict__ out) {
+  const int C8 = C >> 3;
+  const size_t total = (size_t)B * 2 * Ho * 2 * Wo * C8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % C8);
+    size_t r = idx / C8;
+    const int x = (int)(r % (2 * Wo)); r /= 2 * Wo;
+    const int y = (int)(r % (2 * Ho));
+    const int b = (int)(r / (2 * Ho));
+    half8 v = zero_half8();
+    if (!(x & 1) && !(y & 1)) v = ldg_half8(dy + (((size_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + cv * 8);
+    *reinterpret_cast<half8*>(out + idx * 8) = v;
+  }
+}
+int launch_zero_stuff2(const half_t* dy, int B, int Ho, int Wo, int C, half_t* out, hipStream_t st) {
+  if (C & 7) return -3;
+  const size_t total = (size_t)B * 2 * Ho * 2 * Wo * (C >> 3);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  zero_stuff2_kernel<<<blocks, 256, 0, st>>>(dy, B, Ho, Wo, C, out);
+  return (int)hipGetLastError();
+}
+
+// Weight repack for dgrad through the forward kernel.  Forward layout: w[n][tap][c] (N x k*k x Cin, the igemm "weight rows").
+// dgrad of a stride-1, pad-(k/2) convolution is the same convolution of dy with wd[c][k*k - 1 - tap][n]; for k = 1 this is W^T.
+// Npad >= N: the gradient tensor's channel count (conv_out has 4 output channels; its gradient map is stored with 8): columns N .. Npad are 0.
+__global__ void __launch_bounds__(256) repack_dgrad_kernel(const half_t* __restrict__ w, int N, int Npad, int taps, int Cin, half_t* __restrict__ wd) {
+  const size_t total = (size_t)Npad * taps * Cin;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % Npad);
+    size_t r = idx / Npad;
+    const int tp = (int)(r % taps);
+    const int c = (int)(r / taps);
+    wd[idx] = n < N ? w[((size_t)n * taps + (taps - 1 - tp)) * Cin + c] : (half_t)0.f;       // idx = (c * taps + tp) * Npad + n
+  }
+}
+int launch_repack_dgrad(const half_t* w, int N, int Npad, int taps, int Cin, half_t* wd, hipStream_t st) {
+  if (Npad < N) return -3;
+  const size_t total = (size_t)Npad * taps * Cin;
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  repack_dgrad_kernel<<<blocks, 256, 0, st>>>(w, N, Npad, taps, Cin, wd);
+  return (int)hipGetLastError();
+}
+
+// dst[c][r] = src[r][c] for r < R, c < Cc; dst rows are ld_dst long and zero beyond R (GEMM operands need their k-extent padded to 8).
+// 32 x 32 tiles through LDS (+1 padding), 256 threads.
+__global__ void __launch_bounds__(256) transpose_f16_kernel(const half_t* __restrict__ src, int ld_src, int R, int Cc, half_t* __restrict__ dst,
+                                                            int ld_dst) {
+  __shared__ half_t tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < Cc) ? src[(size_t)r * ld_src + c] : (half_t)0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < Cc && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][ty + 8 * i];
+  }
+}
+int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st) {
+  if (R <= 0 || Cc <= 0 || ld_dst < R) return -3;
+  transpose_f16_kernel<<<dim3((ld_dst + 31) / 32, (Cc + 31) / 32), 256, 0, st>>>(src, ld_src, R, Cc, dst, ld_dst);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ loss head and Adam
+// NullInversion.null_optimization's inner iteration (inversion.py:209-218) around the UNet:
+//   eps = eps_u + w (eps_c - eps_u);  rec = c_x x + c_e eps  (prev_step with its two scalars folded by the caller);
+//   loss = mean((rec - target)^2);  d loss / d eps_u = (2 / n) (rec - target) c_e (1 - w).
+// One block: writes the gradient (fp32 in the layout of eps, times `grad_scale`: a power-of-two loss scale that the context-gradient GEMM removes) and the
+// loss (fp32 scalar) the host reads for the reference's early-stop test.
+__global__ void __launch_bounds__(1024) null_text_loss_kernel(const float* __restrict__ eps_u, const float* __restrict__ eps_c, const float* __restrict__ x,
+                                                              const float* __restrict__ target, int n, float w, float c_x, float c_e,
+                                                              float grad_scale, float* __restrict__ d_eps_u, float* __restrict__ loss) {
+  __shared__ float s_l[16];
+  float acc = 0.f;
+  const float k = 2.f / (float)n * c_e * (1.f - w) * grad_scale;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float e = eps_u[i] + w * (eps_c[i] - eps_u[i]);
+    const float d = c_x * x[i] + c_e * e - target[i];
+    acc += d * d;
+    d_eps_u[i] = k * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_l[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s_l[i];
+    *loss = t / (float)n;
+  }
+}
+int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x, float c_e,
+                          float grad_scale, float* d_eps_u, float* loss, hipStream_t st) {
+  if (n <= 0) return -3;
+  null_text_loss_kernel<<<1, 1024, 0, st>>>(eps_u, eps_c, x, target, n, w, c_x, c_e, grad_scale, d_eps_u, loss);
+  return (int)hipGetLastError();
+}
+
+// torch.optim.Adam defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay, no amsgrad), step k >= 1, on fp32 parameters:
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^k) * m / (sqrt(v) / sqrt(1 - b2^k) + eps)
+// g arrives multiplied by 1 / inv_scale (the loss scale); bias corrections are computed on the host in double and passed in.
+__global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                                                        int n, float inv_scale, float step_size, float inv_sqrt_bc2, float eps) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    const float mi = 0.9f * m[i] + 0.1f * gi;
+    const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+int launch_adam_step(float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale, hipStream_t st) {
+  if (n <= 0 || k < 1) return -3;
+  const double bc1 = 1.0 - pow(0.9, (double)k), bc2 = 1.0 - pow(0.999, (double)k);
+  adam_step_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, m, v, g, n, inv_scale, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), 1e-8f);
+  return (int)hipGetLastError();
+}

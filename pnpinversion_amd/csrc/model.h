@@ -160,6 +160,8 @@ struct TextKV {
 
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; int M, N, K, ksize; int cfg = -1, split = 0; int geom[7] = {0, 0, 0, 0, 0, 0, 0}; };
 
+struct Tape;   // activation tape of a differentiable forward (null-text path; api.hip)
+
 struct pnpi_ctx {
   pnpi_model_config cfg;
   int device;
@@ -197,4 +199,5 @@ struct pnpi_ctx {
   std::vector<char> host_stage;
   bool prof_on = false;
   std::vector<ProfRec> prof;
+  Tape* tape = nullptr;          // non-null while a forward is being recorded for a backward pass
 };

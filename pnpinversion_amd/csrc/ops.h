@@ -131,3 +131,22 @@ int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_
 int launch_fill_f32(float* p, int n, float v, hipStream_t st);
 int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents,
                        int nimg, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Activation-gradient kernels of the null-text path (bwd.hip)
+// ---------------------------------------------------------------------------------------------------------------
+int launch_layernorm_bwd(const half_t* x, const half_t* dy, int M, int C, float eps, const float* gamma, half_t* dx, hipStream_t st);
+int launch_groupnorm_bwd(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                         const float* beta, int silu, const half_t* dy, half_t* dx, hipStream_t st);
+int launch_geglu_bwd(const half_t* h, const half_t* dy, int M, int I, half_t* dh, hipStream_t st);
+int launch_softmax_bwd_rows(const float* P, const float* dP, size_t R, int N, int ld, float scale, half_t* dS, hipStream_t st);
+int launch_accumulate_f16(half_t* dst, const half_t* src, size_t n, hipStream_t st);
+int launch_sumpool2x2(const half_t* dup, int B, int H, int W, int C, half_t* dx, hipStream_t st);
+int launch_zero_stuff2(const half_t* dy, int B, int Ho, int Wo, int C, half_t* out, hipStream_t st);
+int launch_repack_dgrad(const half_t* w, int N, int Npad, int taps, int Cin, half_t* wd, hipStream_t st);
+int launch_strided_add_f16(half_t* dst, const half_t* src, int ld, int off, size_t R, int C, int accumulate, hipStream_t st);
+int launch_add_f16_to_f32(float* dst, const half_t* src, size_t n, float scale, hipStream_t st);
+int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x, float c_e,
+                          float grad_scale, float* d_eps_u, float* loss, hipStream_t st);
+int launch_adam_step(float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale, hipStream_t st);
+int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st);

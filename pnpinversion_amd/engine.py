@@ -337,6 +337,39 @@ class NativeEngine:
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int32))
         return ts, ts.ctypes.data_as(C.POINTER(C.c_int))
 
+    def edit_loop_uncond_steps(self, x_T, context4, uncond_steps, ctrls, timesteps, guidance_scale, first_only=False, prox=None, quantile=0.7):
+        """edit_loop with per-step unconditional embeddings [steps, nimg, 77, D] (null-text inversion)."""
+        xT, ctx, us = self._f32(x_T), self._f32(context4), self._f32(uncond_steps)
+        nimg = xT.shape[0]
+        out = torch.empty(nimg, 2, *xT.shape[1:], device=self.device)
+        ts, tsp = self._ts(timesteps)
+        arr = _desc_array(ctrls)
+        mode = {None: 0, "l0": 1, "l1": 2}[prox]
+        self._call("pnpi_edit_loop_uncond_steps", _p(xT), nimg, _p(ctx), arr, len(timesteps), tsp, float(guidance_scale), mode, float(quantile),
+                   _p(us), int(bool(first_only)), _p(out))
+        self._keep = (xT, ctx, us, ts, arr, ctrls)
+        return out
+
+    def unet_context_grad(self, latents, t, context, d_eps):
+        """eps and d loss / d context for ONE row (null-text path groundwork): latents [1,4,h,w], context [1,77,D], d_eps like eps."""
+        lat, ctx, de = self._f32(latents), self._f32(context), self._f32(d_eps)
+        eps, dctx = torch.empty_like(lat), torch.empty_like(ctx)
+        self._call("pnpi_unet_context_grad", _p(lat), int(t), _p(ctx), _p(de), _p(eps), _p(dctx))
+        return eps, dctx
+
+    def null_text_optimize(self, ddim_latents, ctx_uncond, ctx_cond, timesteps, guidance_scale, num_inner_steps=10, epsilon=1e-5):
+        """NullInversion.null_optimization for one image -> ([steps, 1, 77, D] embeddings, [steps] Adam iterations run)."""
+        lat = self._f32(ddim_latents)
+        n = lat.shape[0] - 1
+        cu, cc = self._f32(ctx_uncond), self._f32(ctx_cond)
+        out = torch.empty(n, 1, cu.shape[-2], cu.shape[-1], device=self.device, dtype=torch.float32)
+        its = (C.c_int * n)()
+        ts_keep, ts_ptr = self._ts(timesteps)
+        self._call("pnpi_null_text_optimize", _p(lat), _p(cu), _p(cc), n, ts_ptr, float(guidance_scale), int(num_inner_steps),
+                   float(epsilon), _p(out), its)
+        del ts_keep
+        return out, list(its)
+
     def ddim_invert(self, z0, ctx_cond, timesteps):
         z0, ctx = self._f32(z0), self._f32(ctx_cond)
         n = len(timesteps)

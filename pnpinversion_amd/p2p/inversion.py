@@ -178,8 +178,7 @@ class _SinglePromptInversion:
 
 
 class NullInversion(_SinglePromptInversion):
-    """inversion.py:110-242.  Only num_inner_steps = 0 (what `ddim+p2p` uses, p2p_editor.py:155-156) runs natively: the
-    null-text optimisation itself needs the UNet backward pass."""
+    """inversion.py:110-242.  num_inner_steps = 0 is what `ddim+p2p` uses (p2p_editor.py:155-156); > 0 is null-text inversion."""
 
     @torch.no_grad()
     def ddim_inversion(self, image):
@@ -188,12 +187,15 @@ class NullInversion(_SinglePromptInversion):
         return image_rec, self.ddim_loop(latent)
 
     def null_optimization(self, latents, num_inner_steps, epsilon, guidance_scale):
-        if num_inner_steps != 0:
-            raise NotImplementedError("null-text optimisation needs the UNet backward pass: not built (SURVEY 8f rank 4)")
-        # with zero inner steps the embedding never changes; the reference also walks latent_cur down a 50-step CFG loop whose
-        # result nobody reads (inversion.py:228-230) -- not executed here
-        uncond, _ = self.context.chunk(2)
-        return [uncond[:1]] * self.num_ddim_steps
+        """inversion.py:196-225: the device loop pnpi_null_text_optimize (recording UNet forward, reverse walk to the embedding, Adam)."""
+        uncond, cond = self.context.chunk(2)
+        if num_inner_steps == 0:
+            # the embedding never changes; the reference also walks latent_cur down a 50-step CFG loop whose result nobody reads
+            # (inversion.py:228-230) -- not executed here
+            return [uncond[:1]] * self.num_ddim_steps
+        embs, self.inner_iterations = self.model.engine.null_text_optimize(torch.stack(list(latents)), uncond, cond, self.scheduler.timesteps.numpy(),
+                                                                           guidance_scale, num_inner_steps, epsilon)
+        return [embs[i] for i in range(embs.shape[0])]
 
     def invert(self, image_gt, prompt, guidance_scale, num_inner_steps=10, early_stop_epsilon=1e-5):
         self.init_prompt(prompt)

@@ -52,18 +52,18 @@ def direct_inversion_p2p_guidance_forward_add_target(model, prompt, controller, 
 
 
 def _constant_uncond(uncond_embeddings):
-    """The native loop takes one context for the whole loop.  ddim+p2p and negative-prompt inversion hand over the same
-    embedding for every step (inversion.py:226, 98); a genuinely per-step list (null-text optimisation) is not built."""
+    """ddim+p2p and negative-prompt inversion hand over the same embedding for every step (inversion.py:226, 98): one context for
+    the whole loop (text K / V projected once).  Returns None for a genuinely per-step list (null-text optimisation)."""
     first = uncond_embeddings[0]
     for u in uncond_embeddings[1:]:
         if u is not first and not torch.equal(u, first):
-            raise NotImplementedError("per-step unconditional embeddings (null-text inversion) are not built (SURVEY 8f rank 4)")
+            return None
     return first
 
 
 @torch.no_grad()
 def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 50, guidance_scale=7.5, generator=None, latent=None,
-                         uncond_embeddings=None, prox=None, quantile=0.7, recon=None):
+                         uncond_embeddings=None, prox=None, quantile=0.7, recon=None, single_branch=False):
     """models/p2p/p2p_guidance_forward.py:21-62: the plain Prompt-to-Prompt CFG loop (no direct-inversion offset); one or two
     prompts; `uncond_embeddings` = per-step replacement of the "" embedding."""
     batch_size = len(prompt)
@@ -74,11 +74,15 @@ def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 5
     tok = model.tokenizer
     text_input = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
     text = model.text_encoder(text_input.input_ids.to(model.device))[0]
-    if uncond_embeddings is None:
+    per_step = None
+    const = _constant_uncond(uncond_embeddings) if uncond_embeddings is not None else None
+    if uncond_embeddings is None or const is None or single_branch:
         uncond_input = tok([""] * batch_size, padding="max_length", max_length=text_input.input_ids.shape[-1], return_tensors="pt")
         uncond = model.text_encoder(uncond_input.input_ids.to(model.device))[0]
+        if uncond_embeddings is not None:
+            per_step = torch.stack([u.to(text.device).reshape(1, *u.shape[-2:]) for u in uncond_embeddings])     # [steps, 1, 77, D]
     else:
-        uncond = _constant_uncond(uncond_embeddings).to(text.device).expand(*text.shape)
+        uncond = const.to(text.device).expand(*text.shape)
     latent, latents = init_latent(latent, model, height, width, generator, batch_size)
     model.scheduler.set_timesteps(num_inference_steps)
     if batch_size == 1:   # the kernel batch is [unc_a, unc_b, cond_a, cond_b]: run the single prompt as both rows of a pair
@@ -87,8 +91,23 @@ def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 5
     tables = controller_tables(controller)
     if prox is not None and batch_size != 2:
         raise NotImplementedError("the proximal step takes its quantile over the (source, target) pair")
-    out = model.engine.edit_loop(latent.reshape(1, *latent.shape[-3:]), context[None], None, [tables] if tables is not None else None,
-                                 model.scheduler.timesteps.numpy(), guidance_scale, prox=prox, quantile=quantile, recon=recon)
+    if per_step is not None:      # null-text inversion: the step's embedding on every unconditional row (:56-57) or the first only (:92)
+        if recon is not None:
+            raise NotImplementedError("reconstruction guidance with per-step unconditional embeddings")
+        out = model.engine.edit_loop_uncond_steps(latent.reshape(1, *latent.shape[-3:]), context[None], per_step,
+                                                  [tables] if tables is not None else None, model.scheduler.timesteps.numpy(), guidance_scale,
+                                                  first_only=single_branch, prox=prox, quantile=quantile)
+    else:
+        out = model.engine.edit_loop(latent.reshape(1, *latent.shape[-3:]), context[None], None, [tables] if tables is not None else None,
+                                     model.scheduler.timesteps.numpy(), guidance_scale, prox=prox, quantile=quantile, recon=recon)
     if controller is not None and hasattr(controller, "cur_step"):
         controller.cur_step += num_inference_steps
     return out[0][:batch_size], latent
+
+
+
+def p2p_guidance_forward_single_branch(model, prompt, controller, num_inference_steps: int = 50, guidance_scale=7.5, generator=None,
+                                       latent=None, uncond_embeddings=None):
+    """models/p2p/p2p_guidance_forward.py:65-100: the optimised embedding replaces the "" embedding of the FIRST prompt only."""
+    return p2p_guidance_forward(model, prompt, controller, num_inference_steps, guidance_scale, generator, latent, uncond_embeddings,
+                                single_branch=True)

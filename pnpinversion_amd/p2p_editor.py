@@ -4,8 +4,9 @@ Implemented method strings (Appendix D of SURVEY.md; models/p2p_editor.py:46-135
 every loop variant of it that needs no new kernel -- "ddim+p2p", "negative-prompt-inversion+p2p", the 20
 "directinversion+p2p_guidance_<inv>_<fwd>" strings, "ablation_directinversion_{04,08}+p2p",
 "ablation_directinversion_interval_{2,5,10,24,49}+p2p", "ablation_directinversion_add-target+p2p" / "...add-source+p2p".
-The methods that optimise through the UNet (null-text, null-latent) or need the proximal-guidance select are reference
-method strings that raise NotImplementedError naming what is missing; any other string raises the reference's
+"null-text-inversion+p2p" (and its two aliases), "ablation_null-text-inversion_single_branch+p2p" and
+"null-text-inversion+proximal-guidance" run the device null-text optimisation (pnpi_null_text_optimize); the null-latent variant
+raises NotImplementedError naming what is missing; any other string raises the reference's
 NotImplementedError(f"No edit method named {edit_method}") (models/p2p_editor.py:134-135)."""
 import numpy as np
 from PIL import Image
@@ -14,7 +15,8 @@ from .config import SD1
 from .p2p.attention_control import AttentionStore, make_controller
 from .p2p.inversion import DirectInversion, NegativePromptInversion, NullInversion
 from .p2p.p2p_guidance_forward import (direct_inversion_p2p_guidance_forward,
-                                       direct_inversion_p2p_guidance_forward_add_target, p2p_guidance_forward)
+                                       direct_inversion_p2p_guidance_forward_add_target, p2p_guidance_forward,
+                                       p2p_guidance_forward_single_branch)
 from .p2p.proximal_guidance_forward import proximal_guidance_forward
 from .p2p.attention_control import register_attention_control
 from .pipeline import NativePipeline
@@ -91,10 +93,17 @@ class P2PEditor:
             return self.edit_image_directinversion_add_target(image_path, prompt_src, prompt_tar, **kw)
         if edit_method == "ablation_directinversion_add-source+p2p":
             return self.edit_image_directinversion_add_source(image_path, prompt_src, prompt_tar, **kw)
-        if edit_method in ("null-text-inversion+p2p", "null-text-inversion+p2p_a800", "null-text-inversion+p2p_3090",
-                           "ablation_null-text-inversion_single_branch+p2p", "null-text-inversion+proximal-guidance",
-                           "ablation_null-latent-inversion+p2p"):
-            raise NotImplementedError(f"{edit_method}: optimises through the UNet (backward pass); not built (SURVEY 8f rank 4)")
+        if edit_method in ("null-text-inversion+p2p", "null-text-inversion+p2p_a800", "null-text-inversion+p2p_3090"):
+            return self.edit_image_null_text_inversion(image_path, prompt_src, prompt_tar, **kw)
+        if edit_method == "ablation_null-text-inversion_single_branch+p2p":
+            return self.edit_image_null_text_inversion_single_branch(image_path, prompt_src, prompt_tar, **kw)
+        if edit_method == "null-text-inversion+proximal-guidance":
+            return self.edit_image_null_text_inversion_proximal_guidanca(image_path, prompt_src, prompt_tar, proximal=proximal, quantile=quantile,
+                                                                         use_reconstruction_guidance=use_reconstruction_guidance,
+                                                                         recon_t=recon_t, recon_lr=recon_lr,
+                                                                         use_inversion_guidance=use_inversion_guidance, dilate_mask=dilate_mask, **kw)
+        if edit_method == "ablation_null-latent-inversion+p2p":
+            return self.edit_image_null_latent_inversion(image_path, prompt_src, prompt_tar, **kw)
         if edit_method == "negative-prompt-inversion+proximal-guidance":
             return self.edit_image_negative_prompt_inversion(image_path, prompt_src, prompt_tar, proximal=proximal, quantile=quantile,
                                                              use_reconstruction_guidance=use_reconstruction_guidance,
@@ -213,6 +222,49 @@ class P2PEditor:
         fwd = lambda **k: p2p_guidance_forward(num_inference_steps=self.num_ddim_steps, **k)   # noqa: E731
         return self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                                self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
+
+    def edit_image_null_text_inversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
+                                       self_replace_steps=0.6, blend_word=None, eq_params=None, is_replace_controller=False,
+                                       single_branch=False, proximal=None, quantile=0.7, use_reconstruction_guidance=False,
+                                       num_inner_steps=10, return_stages=False):
+        """models/p2p_editor.py:199-259 (null-text inversion + P2P), :261-322 (single branch), :550-638 (+ proximal guidance with the
+        arguments run_editing_p2p.py passes): NullInversion.invert = DDIM inversion + per-step optimisation of the unconditional
+        embedding (pnpi_null_text_optimize), then the two plain guidance passes with the per-step embeddings."""
+        if use_reconstruction_guidance:
+            raise NotImplementedError("reconstruction guidance with per-step unconditional embeddings is not built")
+        image_gt, side = self._load(image_path)
+        self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
+        inv = NullInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
+        _, _, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, guidance_scale=guidance_scale,
+                                                      num_inner_steps=num_inner_steps)
+        base = p2p_guidance_forward_single_branch if single_branch else p2p_guidance_forward
+
+        def fwd(**k):   # the reconstruction pass runs without the proximal step (edit_stage=False, p2p_editor.py:577-594)
+            if proximal is not None and len(k["prompt"]) == 2:
+                return proximal_guidance_forward(num_inference_steps=self.num_ddim_steps, edit_stage=True, prox=proximal, quantile=quantile, **k)
+            return base(num_inference_steps=self.num_ddim_steps, **k)
+        out = self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
+                              self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
+        if return_stages:
+            out[1]["uncond_embeddings"] = uncond_embeddings
+        return out
+
+    def edit_image_null_text_inversion_single_branch(self, image_path, prompt_src, prompt_tar, **kw):
+        """models/p2p_editor.py:261-322"""
+        return self.edit_image_null_text_inversion(image_path, prompt_src, prompt_tar, single_branch=True, **kw)
+
+    def edit_image_null_text_inversion_proximal_guidanca(self, image_path, prompt_src, prompt_tar, proximal=None, quantile=0.7,
+                                                         use_reconstruction_guidance=False, recon_t=400, recon_lr=0.1,
+                                                         use_inversion_guidance=False, dilate_mask=1, **kw):
+        """models/p2p_editor.py:550-638 (the reference's spelling).  recon_* / use_inversion_guidance / dilate_mask only matter with
+        reconstruction guidance (image_enc is None otherwise, and the inversion-guidance branch is dead code: :87-89 precedence)."""
+        return self.edit_image_null_text_inversion(image_path, prompt_src, prompt_tar, proximal=proximal, quantile=quantile,
+                                                   use_reconstruction_guidance=use_reconstruction_guidance, **kw)
+
+    def edit_image_null_latent_inversion(self, image_path, prompt_src, prompt_tar, **kw):
+        """models/p2p_editor.py:640-705"""
+        raise NotImplementedError("ablation_null-latent-inversion+p2p: the two-prompt latent-offset variant of the null-text optimisation is "
+                                  "not built (DirectInversion.null_latent_calculate, inversion.py:418-460)")
 
     def edit_image_negative_prompt_inversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None,
                                              quantile=0.7, use_reconstruction_guidance=False, recon_t=400, recon_lr=0.1, npi_interp=0,

@@ -1,0 +1,279 @@
+"""Activation-gradient kernels of the null-text path (pnpinversion_amd/csrc/bwd.hip) through the C ABI against torch.autograd on the
+fp32 op of the forward (NullInversion.null_optimization's loss.backward(), models/p2p/inversion.py:196-225).  Groundwork: kernel level
+only -- no method string of P2PEditor reaches these kernels yet."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import Ctx, ptr, rel_err  # noqa: E402
+from tests.test_gpu_kernels import h16, ilv32, nhwc, pack_w  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Ctx()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("M,C", [(1024, 320), (100, 1280), (7, 32), (64, 640)])
+def test_layernorm_bwd(ctx, M, C):
+    x = (h16(M, C, seed=1).float() * 3 + 1).half()
+    dy = h16(M, C, seed=2)
+    gamma = torch.randn(C, device=DEV) * 0.2 + 1
+    beta = torch.randn(C, device=DEV) * 0.2
+    xr = x.float().requires_grad_(True)
+    F.layer_norm(xr, (C,), gamma, beta, 1e-5).backward(dy.float())
+    dx = torch.zeros(M, C, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_layernorm_bwd", ptr(x), ptr(dy), M, C, 1e-5, ptr(gamma), ptr(dx))
+    assert rel_err(dx, xr.grad) < 3e-3, rel_err(dx, xr.grad)
+
+
+@pytest.mark.parametrize("B,C1,C2,HW,silu,eps", [(1, 320, 0, 4096, 1, 1e-5), (2, 64, 32, 64, 1, 1e-6), (1, 1280, 640, 256, 1, 1e-5),
+                                                 (1, 1280, 0, 64, 0, 1e-6), (3, 32, 0, 16, 1, 1e-5)])
+def test_groupnorm_bwd(ctx, B, C1, C2, HW, silu, eps):
+    C = C1 + C2
+    x1 = (h16(B, HW, C1, seed=3).float() * 2 + 0.5).half()
+    x2 = h16(B, HW, C2, seed=4) if C2 else None
+    dy = h16(B, HW, C, seed=5)
+    gamma = torch.randn(C, device=DEV) * 0.2 + 1
+    beta = torch.randn(C, device=DEV) * 0.2
+    xin = (x1 if x2 is None else torch.cat([x1, x2], 2)).float().requires_grad_(True)
+    y = F.group_norm(xin.permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy.float().permute(0, 2, 1))
+    dx = torch.zeros(B, HW, C, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_groupnorm_bwd", ptr(x1), ptr(x2) if C2 else None, C1, C2, B, HW, 32, eps, ptr(gamma), ptr(beta), silu, ptr(dy), ptr(dx))
+    assert rel_err(dx, xin.grad) < 4e-3, rel_err(dx, xin.grad)
+
+
+def test_geglu_bwd(ctx):
+    M, I = 333, 256
+    a = h16(M, I, scale=2.0, seed=6)
+    g = h16(M, I, scale=2.0, seed=7)
+    dy = h16(M, I, seed=8)
+    ar, gr = a.float().requires_grad_(True), g.float().requires_grad_(True)
+    (ar * F.gelu(gr)).backward(dy.float())
+    h = ilv32(a, g).contiguous()
+    dh = torch.zeros(M, 2 * I, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_geglu_bwd", ptr(h), ptr(dy), M, I, ptr(dh))
+    assert rel_err(dh, ilv32(ar.grad, gr.grad)) < 3e-3, rel_err(dh, ilv32(ar.grad, gr.grad))
+
+
+@pytest.mark.parametrize("R,N", [(64, 77), (300, 256), (5, 4096)])
+def test_softmax_bwd_rows(ctx, R, N):
+    g = torch.Generator(device="cpu").manual_seed(9)
+    S = (torch.randn(R, N, generator=g) * 2).to(DEV).requires_grad_(True)
+    dP = torch.randn(R, N, generator=g).to(DEV)
+    P = torch.softmax(S, -1)
+    P.backward(dP)
+    ld = (N + 7) // 8 * 8
+    dS = torch.full((R, ld), float("nan"), dtype=torch.half, device=DEV)
+    Pd = P.detach().contiguous()
+    ctx.call("pnpi_op_softmax_bwd_rows", ptr(Pd), ptr(dP), R, N, ld, 0.125, ptr(dS))
+    assert rel_err(dS[:, :N], 0.125 * S.grad) < 3e-3
+    assert (dS[:, N:] == 0).all()
+
+
+def test_accumulate_sumpool_zero_stuff(ctx):
+    a, b = h16(4096 * 8, seed=10), h16(4096 * 8, seed=11)
+    want = (a.float() + b.float()).half()
+    ctx.call("pnpi_op_accumulate", ptr(a), ptr(b), a.numel())
+    assert torch.equal(a, want)
+    B, H, W, Cc = 2, 6, 5, 64
+    x = h16(B, Cc, H, W, seed=12).float().requires_grad_(True)
+    dup = h16(B, Cc, 2 * H, 2 * W, seed=13)
+    F.interpolate(x, scale_factor=2.0, mode="nearest").backward(dup.float())
+    dupn = nhwc(dup)
+    dx = torch.zeros(B, H, W, Cc, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_sumpool2x2", ptr(dupn), B, H, W, Cc, ptr(dx))
+    assert rel_err(dx.permute(0, 3, 1, 2), x.grad) < 2e-3
+    dy = nhwc(h16(B, Cc, H, W, seed=14))
+    z = torch.full((B, 2 * H, 2 * W, Cc), float("nan"), dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_zero_stuff2", ptr(dy), B, H, W, Cc, ptr(z))
+    assert torch.equal(z[:, ::2, ::2], dy) and (z[:, 1::2] == 0).all() and (z[:, :, 1::2] == 0).all()
+
+
+@pytest.mark.parametrize("B,Cin,H,N,ks,stride", [(2, 64, 16, 128, 3, 1), (1, 320, 8, 64, 3, 1), (3, 128, 8, 64, 1, 1), (2, 64, 16, 64, 3, 2)])
+def test_conv_dgrad_through_the_forward_kernel(ctx, B, Cin, H, N, ks, stride):
+    """dx of conv2d = the forward implicit-GEMM kernel on dy with the weights repacked by pnpi_op_repack_dgrad (stride 2: after
+    pnpi_op_zero_stuff2) -- no dedicated dgrad kernel."""
+    pad = ks // 2
+    x = h16(B, Cin, H, H, seed=15).float().requires_grad_(True)
+    w = h16(N, Cin, ks, ks, scale=1.0 / math.sqrt(ks * ks * Cin), seed=16)
+    y = F.conv2d(x, w.float(), None, stride=stride, padding=pad)
+    Ho = y.shape[2]
+    dy = h16(B, N, Ho, Ho, seed=17)
+    y.backward(dy.float())
+    wp = pack_w(w)                                                       # [N][taps * Cin]
+    wd = torch.zeros(Cin, ks * ks * N, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_repack_dgrad", ptr(wp), N, ks * ks, Cin, ptr(wd))
+    dyn = nhwc(dy)
+    if stride == 2:
+        z = torch.zeros(B, 2 * Ho, 2 * Ho, N, dtype=torch.half, device=DEV)
+        ctx.call("pnpi_op_zero_stuff2", ptr(dyn), B, Ho, Ho, N, ptr(z))
+        dyn, Hi = z, 2 * Ho
+    else:
+        Hi = Ho
+    assert Hi == H
+    dx = torch.zeros(B, H, H, Cin, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_conv", ptr(dyn), None, N, 0, B, Hi, Hi, ks, 1, pad, 0, H, H, ptr(wd), None, None, Cin, ptr(dx), -1, 0)
+    torch.cuda.synchronize()
+    assert rel_err(dx.permute(0, 3, 1, 2), x.grad) < 3e-3, rel_err(dx.permute(0, 3, 1, 2), x.grad)
+
+
+def test_null_text_loss_head_and_adam(ctx):
+    n = 4 * 64 * 64
+    g = torch.Generator(device="cpu").manual_seed(18)
+    eu, ec, x, tgt = [torch.randn(n, generator=g).to(DEV) for _ in range(4)]
+    w, c_x, c_e, scale = 7.5, 1.0172, -0.0831, 1024.0
+    eur = eu.clone().requires_grad_(True)
+    rec = c_x * x + c_e * (eur + w * (ec - eur))
+    loss = F.mse_loss(rec, tgt)
+    loss.backward()
+    d = torch.zeros(n, device=DEV)
+    lv = torch.zeros(1, device=DEV)
+    ctx.call("pnpi_op_null_text_loss", ptr(eu), ptr(ec), ptr(x), ptr(tgt), n, w, c_x, c_e, scale, ptr(d), ptr(lv))
+    assert abs(lv.item() - loss.item()) < 1e-5 * abs(loss.item())
+    assert rel_err(d / scale, eur.grad) < 1e-5
+    # Adam: three steps against torch.optim.Adam on the same gradients (scaled by 1024 on the device side)
+    p = torch.randn(77 * 768, generator=g).to(DEV)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-2 * (1 - 3 / 100.0))
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for k in range(1, 4):
+        gk = torch.randn(p.numel(), generator=g).to(DEV) * 1e-3
+        pr.grad = gk.clone()
+        opt.step()
+        gs = (gk * scale).contiguous()
+        ctx.call("pnpi_op_adam_step", ptr(p), ptr(m), ptr(v), ptr(gs), p.numel(), k, 1e-2 * (1 - 3 / 100.0), 1.0 / scale)
+        assert (p - pr.detach()).abs().max().item() < 2e-6, (k, (p - pr.detach()).abs().max().item())
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,dh,Dp", [(1, 2, 64, 77, 40, 64), (2, 8, 256, 256, 8, 32), (1, 8, 1024, 1024, 40, 64), (1, 4, 4, 77, 160, 160)])
+def test_attention_bwd_materialised(ctx, B, heads, Nq, Nk, dh, Dp):
+    """dq / dk / dv of softmax(scale q k^T) v per (row, head) -- self-attention shapes and the 77-key cross-attention -- against autograd."""
+    g = torch.Generator(device="cpu").manual_seed(20)
+    scale = 1.0 / math.sqrt(dh)
+
+    def padded(n):
+        t = torch.zeros(B, n, heads, Dp)
+        t[..., :dh] = torch.randn(B, n, heads, dh, generator=g)
+        return t.reshape(B * n, heads * Dp).half().to(DEV)
+
+    q, k, v = padded(Nq), padded(Nk), padded(Nk)
+    d_o = torch.randn(B * Nq, heads * dh, generator=g).half().to(DEV)
+    qr, kr, vr = [t.float().reshape(B, -1, heads, Dp)[..., :dh].permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v)]
+    o = torch.softmax(scale * qr @ kr.transpose(-1, -2), -1) @ vr                         # [B, heads, Nq, dh]
+    o.backward(d_o.float().reshape(B, Nq, heads, dh).permute(0, 2, 1, 3))
+    dq, dk, dv = [torch.zeros_like(t) for t in (q, k, v)]
+    nbytes = ctx.lib.pnpi_op_attention_bwd_scratch_bytes(Nq, Nk, dh)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    ctx.call("pnpi_op_attention_bwd", ptr(q), heads * Dp, 0, ptr(k), heads * Dp, 0, ptr(v), heads * Dp, 0, ptr(d_o), heads * dh, heads, Nq, Nk, Dp, dh,
+             scale, B, ptr(dq), ptr(dk), ptr(dv), ptr(scratch), nbytes)
+    torch.cuda.synchronize()
+    for got, ref, n in ((dq, qr.grad, Nq), (dk, kr.grad, Nk), (dv, vr.grad, Nk)):
+        gh = got.float().reshape(B, n, heads, Dp)
+        assert (gh[..., dh:] == 0).all()                                                  # pad columns untouched
+        assert rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref) < 6e-3, rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref)
+
+
+# ------------------------------------------------------------------------------------------------ whole-UNet context gradient, null-text loop
+def test_unet_context_gradient_against_oracle_autograd():
+    """pnpi_unet_context_grad (recording forward + reverse walk over the ops) vs torch.autograd through the CPU oracle's UNet, TINY16."""
+    import numpy as np
+    from oracle import sd_oracle
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import TINY16
+    from pnpinversion_amd.engine import NativeEngine
+    cfg = TINY16
+    usd, vsd = weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1)
+    eng = NativeEngine(cfg, max_unet_rows=12, max_vae_images=1)
+    eng.load_state_dict(usd, vsd)
+    g = torch.Generator().manual_seed(31)
+    lat = torch.randn(1, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g)
+    ctx = weights.synth_context(cfg, 1, seed=32).cpu()
+    d_eps = torch.randn(1, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g)
+    cr = ctx.clone().requires_grad_(True)
+    eps_ref = sd_oracle.unet_forward(usd, cfg, lat, 500, cr)
+    eps_ref.backward(d_eps)
+    scale = 256.0
+    eps, dctx = eng.unet_context_grad(lat.cuda(), 500, ctx.cuda(), (d_eps * scale).cuda())
+    assert rel_err(eps, eps_ref.detach()) < 4e-3
+    got = dctx.cpu() / scale
+    assert torch.isfinite(got).all()
+    assert rel_err(got, cr.grad) < 3e-2, rel_err(got, cr.grad)
+    # a plain forward afterwards is unaffected by the tape
+    assert rel_err(eng.unet(lat.cuda(), 500, ctx.cuda()), eps_ref.detach()) < 4e-3
+    eng.close()
+
+
+def test_null_text_optimize_against_reference_golden():
+    """pnpi_null_text_optimize vs the reference's own NullInversion.invert on the 128 x 128 crop (tests/golden/null_text_family_tiny.npz):
+    ten Adam iterations per step, three steps.  fp16 activation gradients: the embeddings' MOVE is compared, not only the embeddings."""
+    import os
+    import numpy as np
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import TINY16
+    from pnpinversion_amd.engine import NativeEngine
+    from pnpinversion_amd.p2p.scheduler_dev import DDIMSchedulerDev
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "null_text_family_tiny.npz"))
+    cfg, steps = TINY16, int(gold["steps"])
+    eng = NativeEngine(cfg, max_unet_rows=12, max_vae_images=1)
+    eng.load_state_dict(weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1))
+    sch = DDIMSchedulerDev(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    sch.bind(eng)
+    sch.set_timesteps(steps)
+    x_stars = torch.from_numpy(gold["x_stars"]).cuda()                 # [steps + 1, 1, 4, 16, 16]
+    ctx2 = torch.from_numpy(gold["context"]).float().cuda()
+    ref = torch.from_numpy(gold["uncond_embeddings"])                 # [steps, 1, 77, D]
+    got, its = eng.null_text_optimize(x_stars, ctx2[:1], ctx2[1:], sch.timesteps.numpy(), 7.5, num_inner_steps=10, epsilon=1e-5)
+    assert its == [10] * steps
+    got = got.cpu()
+    base = ctx2[:1].cpu()
+    assert rel_err(got, ref) < 5e-3, rel_err(got, ref)
+    assert rel_err(got[0] - base, ref[0] - base) < 8e-2, rel_err(got[0] - base, ref[0] - base)      # the first step's update itself
+    eng.close()
+
+
+def test_null_text_editor_against_reference_golden():
+    """P2PEditor("null-text-inversion+p2p") end to end against the reference's own run (tests/golden/e2e_null_text.npz: SMALL64, 3 steps,
+    10 Adam iterations each, Refine + Reweight + LocalBlend): inversion latents, per-step embeddings, reconstruction and edited latents."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import SMALL64
+    from pnpinversion_amd.p2p_editor import P2PEditor
+    from pnpinversion_amd.pipeline import NativePipeline
+    from pnpinversion_amd.text import SyntheticTextEncoder
+    GOLD = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(GOLD, "e2e_null_text.npz"))
+    cfg, steps = SMALL64, int(g["steps"])
+    pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    ed = P2PEditor(["null-text-inversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=pipe)
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    w0, w1 = [str(x) for x in g["blend"]]
+    panel, st = ed.edit_image_null_text_inversion(img, str(g["src"]), str(g["tgt"]), blend_word=((w0,), (w1,)),
+                                                  eq_params={"words": (w1,), "values": (2,)}, return_stages=True)
+    assert panel.size == (2048, 512)
+    xs = torch.stack([x for x in st["x_stars"]]).cpu()
+    assert rel_err(xs, torch.from_numpy(g["x_stars"])) < 5e-3
+    unc = torch.stack([u for u in st["uncond_embeddings"]]).cpu()
+    ref_unc = torch.from_numpy(g["uncond_embeddings"])
+    assert rel_err(unc, ref_unc) < 1e-2, rel_err(unc, ref_unc)
+    assert rel_err(st["reconstruct_latent"].cpu(), torch.from_numpy(g["reconstruct_latent"])) < 5e-2
+    assert rel_err(st["latents"].cpu()[:1], torch.from_numpy(g["edited_latents"])[:1]) < 5e-2
+    # the dispatch reaches the same method; the null-latent variant still names what is missing
+    with pytest.raises(NotImplementedError, match="null-latent"):
+        ed("ablation_null-latent-inversion+p2p", image_path=img, prompt_src=str(g["src"]), prompt_tar=str(g["tgt"]))
+    pipe.engine.close()

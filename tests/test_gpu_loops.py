@@ -347,9 +347,8 @@ def test_editor_method_variants_against_reference_golden(small64, method, lockst
 def test_unbuilt_reference_methods_say_so(small64):
     ed = P2PEditor(["x"], "cuda", num_ddim_steps=2, pipeline=small64)
     img = np.zeros((64, 64, 3), np.uint8)
-    for m in ("null-text-inversion+p2p", "null-text-inversion+proximal-guidance", "ablation_null-latent-inversion+p2p"):
-        with pytest.raises(NotImplementedError, match="not built"):
-            ed(m, img, "a", "b")
+    with pytest.raises(NotImplementedError, match="not built"):
+        ed("ablation_null-latent-inversion+p2p", img, "a", "b")
     with pytest.raises(NotImplementedError, match="No edit method named"):
         ed("directinversion+p2p_guidance_9_9", img, "a", "b")
 

@@ -81,8 +81,8 @@ def test_controller_descriptor_semantics():
 
 def test_method_dispatch_matches_reference():
     """P2PEditor.__call__: every one of the reference's 39 method strings goes to the handler, with the method-specific arguments,
-    that the reference's own __call__ (models/p2p_editor.py:28-135) uses (tests/golden/method_dispatch.json); the six that need
-    the UNet backward pass say so; anything else raises the reference's NotImplementedError message."""
+    that the reference's own __call__ (models/p2p_editor.py:28-135) uses (tests/golden/method_dispatch.json); anything else raises the
+    reference's NotImplementedError message.  (The null-latent handler exists and says what is missing.)"""
     import json
     import types
     from pnpinversion_amd.p2p_editor import P2PEditor
@@ -91,10 +91,10 @@ def test_method_dispatch_matches_reference():
     ed = P2PEditor(["x"], "cpu", num_ddim_steps=50, pipeline=fake)
     for n in [n for n in dir(P2PEditor) if n.startswith("edit_image")]:
         setattr(ed, n, (lambda n: (lambda *a, **k: (n, k)))(n))
-    unbuilt = {"null-text-inversion+p2p", "null-text-inversion+p2p_a800", "null-text-inversion+p2p_3090",
-               "ablation_null-text-inversion_single_branch+p2p", "null-text-inversion+proximal-guidance",
-               "ablation_null-latent-inversion+p2p"}
+    unbuilt = set()     # every string reaches its handler (edit_image_null_latent_inversion itself raises: checked below)
     assert len(gold) == 40
+    with pytest.raises(NotImplementedError, match="not built"):
+        P2PEditor.edit_image_null_latent_inversion(ed, "x", "a", "b")
     for m, want in gold.items():
         if m == "__unknown__":
             with pytest.raises(NotImplementedError) as ei:
