@@ -120,6 +120,8 @@ typedef struct {
                                       each for SD-1.x); a forward that reads the cache does NOT execute them: its sample-forward is
                                       803.27 - 2.95 GFLOP */
   uint64_t unet_sample_forwards_cached_kv;   /* of unet_sample_forwards, the rows that read the text K / V cache */
+  uint64_t unet_backward_rows;     /* reverse walks (d loss / d context through one UNet row: null-text / null-latent inversion); the
+                                      recording forward of each is counted in unet_sample_forwards */
 } pnpi_counters;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
@@ -318,7 +320,8 @@ size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh);
  * a power-of-two loss scale -- activation gradients travel in fp16 -- and divide d_context_out by it).  eps_out nullable.
  * pnpi_null_text_optimize: NullInversion.null_optimization (models/p2p/inversion.py:196-225) for one image: ddim_latents
  * [nsteps + 1][4*h*w] (x*_0 first), the "" and the source-prompt embeddings, the denoising timesteps; uncond_out [nsteps][77][768]
- * (the optimised embedding of every step), iters_out [nsteps] (nullable: Adam iterations run per step).  Context needs
+ * (the optimised embedding of every step), iters_out [nsteps] (nullable: Adam iterations run per step), losses_out_host
+ * [nsteps][num_inner_steps] (nullable, host: the loss of every Adam iteration, -1 where the early stop skipped it).  Context needs
  * max_unet_rows large enough for one row's activations kept without reuse (12 is). */
 /* pnpi_edit_loop with per-step unconditional embeddings uncond_steps [nsteps][nimg][77][768] (the output of pnpi_null_text_optimize):
  * p2p_guidance_forward's `uncond_embeddings[i].expand(...)` (p2p_guidance_forward.py:56-57), or with uncond_first_only the single-branch
@@ -330,7 +333,14 @@ int pnpi_unet_context_grad(pnpi_ctx* ctx, const float* latents, int t, const flo
                            float* d_context_out);
 int pnpi_null_text_optimize(pnpi_ctx* ctx, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,
                             const int* timesteps_host, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out,
-                            int* iters_out_host);
+                            int* iters_out_host, float* losses_out_host);
+/* replaces DirectInversion.null_latent_calculate                               models/p2p/inversion.py:419-460
+ * ("ablation_null-latent-inversion+p2p"): the null-text optimisation of the source row's unconditional embedding per step, turned into
+ * per-step latent offsets noise_loss_out [nsteps][2][4*h*w] (device) for pnpi_edit_loop.  context4 = [unc_src, unc_tgt, cond_src,
+ * cond_tgt]; iters_out_host [nsteps] and losses_out_host [nsteps][num_inner_steps] nullable (host; -1 = iteration not run). */
+int pnpi_null_latent_calculate(pnpi_ctx* ctx, const float* ddim_latents, const float* context4, int nsteps, const int* timesteps_host,
+                               float guidance_scale, int num_inner_steps, float epsilon, float* noise_loss_out, int* iters_out_host,
+                               float* losses_out_host);
 int pnpi_op_attention(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const void* k, int ldk, int k_off, const void* vt,
                       int ldv, void* o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale,
                       const int* rows_dev /*[nrows][4]*/, int nrows);

@@ -12,6 +12,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
   e2e_replace.npz      same with is_replace_controller=True (AttentionReplace), no blend / reweight
   e2e_insert2/3.npz    same as e2e_refine for prompt pairs whose target INSERTS tokens (refinement mapper -1 / alpha 0 entries)
   e2e_sd1.npz          same as e2e_refine at the FULL SD-1.x width (the benchmarked configuration), weight seed 0
+  e2e_sd1_50.npz       the same at the benchmarked SCHEDULE too: full width, 50 + 50 steps (every 10th inversion latent / offset kept)
   e2e_variants.npz     the reference's P2PEditor run on six more method strings that share the loop (ddim+p2p,
                        negative-prompt-inversion+p2p, a vary-guidance, a not_full, a skip_step and the add-target ablation):
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
@@ -115,8 +116,9 @@ def model_goldens():
         print("model goldens", name, "%.1fs" % (time.time() - t0))
 
 
-def e2e(name, is_replace, blend, steps=2, cfg=SMALL64, seed=2, pair=None):
-    """pair: index into PROMPT_PAIRS (default: 1 for the Replace controller, which needs equal word counts, else 0).  Pairs 2 and
+def e2e(name, is_replace, blend, steps=2, cfg=SMALL64, seed=2, pair=None, keep_every=1):
+    """keep_every > 1 (the 50 + 50-step full-width fixture): only every keep_every-th inversion latent / offset is stored
+    (plus the last ones), so the committed file stays small.  pair: index into PROMPT_PAIRS (default: 1 for the Replace controller, which needs equal word counts, else 0).  Pairs 2 and
     3 insert tokens into the target prompt (seq_aligner.get_mapper's -1 / alpha 0 entries).  cfg=SD1 is the benchmarked width."""
     ref_shim.install()
     t0 = time.time()
@@ -161,7 +163,15 @@ def e2e(name, is_replace, blend, steps=2, cfg=SMALL64, seed=2, pair=None):
         pe.direct_inversion_p2p_guidance_forward = orig_fwd
     panel = np.array(panel)
     S = 512
-    np.savez_compressed(os.path.join(OUT, "e2e_%s.npz" % name), x_stars=stages["x_stars"], noise_loss=stages["noise_loss"],
+    kept = {}
+    if keep_every > 1:
+        # x_stars[j] for j in xs_idx (always the end points); noise_loss[i] for i in nl_idx
+        xs_idx = sorted(set(list(range(0, steps + 1, keep_every)) + [steps]))
+        nl_idx = sorted(set(list(range(0, steps, keep_every)) + [steps - 1]))
+        stages["x_stars"] = stages["x_stars"][xs_idx]
+        stages["noise_loss"] = stages["noise_loss"][nl_idx]
+        kept = dict(x_stars_index=np.array(xs_idx, np.int64), noise_loss_index=np.array(nl_idx, np.int64))
+    np.savez_compressed(os.path.join(OUT, "e2e_%s.npz" % name), x_stars=stages["x_stars"], noise_loss=stages["noise_loss"], **kept,
                         context=stages["context"].astype(np.float16), reconstruct_latent=calls[0], edited_latents=calls[1],
                         recon_image_small=panel[::4, 2 * S:3 * S:4], edited_image_small=panel[::4, 3 * S::4],
                         src=src, tgt=tgt, blend=np.array([w0, w1]), steps=np.int64(steps), is_replace=np.bool_(is_replace),
@@ -592,7 +602,7 @@ def masactrl(steps=6, start_step=2, start_layer=10):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("PNPI_GOLDEN_THREADS", os.cpu_count())))
     which = sys.argv[1:] or ["host", "models", "e2e", "variants", "masactrl", "proximal", "clip", "dispatch"]
     if "host" in which:
         host_tables()
@@ -608,6 +618,10 @@ if __name__ == "__main__":
     if "e2e_sd1" in which or not sys.argv[1:]:
         # the benchmarked configuration: full SD-1.x width (859.5 M parameters), the reference's own P2PEditor, 2 + 2 steps
         e2e("sd1", False, True, steps=2, cfg=SD1, seed=0)
+    if "e2e_sd1_50" in which:
+        # the benchmarked configuration AND the benchmarked schedule: full SD-1.x width, 50 + 50 steps (about 45-60 min of CPU;
+        # not part of the default list)
+        e2e("sd1_50", False, True, steps=50, cfg=SD1, seed=0, keep_every=10)
     if "variants" in which:
         variants()
     if "masactrl" in which:

@@ -47,7 +47,7 @@ ATTN_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C
 class Counters(C.Structure):
     _fields_ = [("unet_sample_forwards", C.c_uint64), ("unet_calls", C.c_uint64), ("vae_encodes", C.c_uint64),
                 ("vae_decodes", C.c_uint64), ("executed_gemm_flops", C.c_double), ("executed_attn_flops", C.c_double),
-                ("text_kv_rows", C.c_uint64), ("unet_sample_forwards_cached_kv", C.c_uint64)]
+                ("text_kv_rows", C.c_uint64), ("unet_sample_forwards_cached_kv", C.c_uint64), ("unet_backward_rows", C.c_uint64)]
 
 
 KC_NAMES = ["igemm128", "igemm64", "igemm64_splitk", "attn_flash", "attn_cross_edit", "groupnorm", "layernorm", "geglu", "softmax", "igemm_wide"]
@@ -118,7 +118,8 @@ SYMBOLS = {
     "pnpi_op_attention_bwd_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "pnpi_edit_loop_uncond_steps": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, _i, _vp]),
     "pnpi_unet_context_grad": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "pnpi_null_text_optimize": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, C.POINTER(C.c_int)]),
+    "pnpi_null_text_optimize": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "pnpi_null_latent_calculate": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "pnpi_op_attention": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i]),
     "pnpi_op_cross_edit": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp,
                                 _vp, _vp, _vp, _i, _i]),

@@ -1015,7 +1015,18 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
         break;
       }
       case TK_ATTN: {
-        const size_t need = attn_bwd_scratch_bytes(o.Nq, o.Nk, o.dh);
+        // head widths that are not a multiple of 8 (reduced test configurations only): the gradient of the attention output is
+        // re-laid out with Dp-wide heads (zero pads) and the whole backward runs on the padded width -- q / k / v pads are zero
+        const bool pad_dh = (o.dh & 7) != 0;
+        const int dh_eff = pad_dh ? o.Dp : o.dh;
+        int ldo_eff = o.ldo;
+        if (pad_dh) {
+          half_t* dyp = tape_galloc(c, (size_t)o.B * o.Nq * o.heads * o.Dp);
+          if (!dyp) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+          CK(launch_pad_heads_f16(dy, (size_t)o.B * o.Nq, o.heads, o.dh, o.Dp, dyp, c->st));
+          dy = dyp; ldo_eff = o.heads * o.Dp;
+        }
+        const size_t need = attn_bwd_scratch_bytes(o.Nq, o.Nk, dh_eff);
         if (need > T.attn_scratch_bytes) {
           if (T.attn_scratch) CKH(hipFree(T.attn_scratch));
           T.attn_scratch = nullptr; T.attn_scratch_bytes = 0;
@@ -1039,7 +1050,7 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
         CKP(grad_of(o.k, (size_t)o.B * o.Nk * o.ldk, &gk));
         CKP(grad_of(o.v, (size_t)o.B * o.Nk * o.ldv, &gv));
         // (the projection outputs have exactly one consumer each -- this attention -- so the kernels may overwrite, not accumulate)
-        CKP(attn_bwd_materialized(c, o.q, o.ldq, o.q_off, o.k, o.ldk, o.k_off, o.v, o.ldv, o.v_off, dy, o.ldo, o.heads, o.Nq, o.Nk, o.Dp, o.dh,
+        CKP(attn_bwd_materialized(c, o.q, o.ldq, o.q_off, o.k, o.ldk, o.k_off, o.v, o.ldv, o.v_off, dy, ldo_eff, o.heads, o.Nq, o.Nk, o.Dp, dh_eff,
                                   o.scale, o.B, gq, gk, gv, T.attn_scratch, T.attn_scratch_bytes));
         break;
       }
@@ -2242,75 +2253,155 @@ int pnpi_unet_context_grad(pnpi_ctx* c, const float* latents, int t, const float
   return 0;
 }
 
+// The Adam loop both optimisations share (inversion.py:203-218 and :430-447): eps_c = UNet(lat, t, ctx_cond) once, then up to
+// num_inner_steps x {recording forward with the current embedding `unc`, loss = mse(prev_step(CFG), target) and its gradient, reverse
+// walk to the embedding, Adam (torch.optim.Adam defaults, state fresh per DDIM step)}; the loss is read back for the reference's
+// early-stop test `loss < epsilon + i * 2e-5`.  eps2 = [eps_u | eps_c] (2E floats).  losses_host (nullable): [num_inner_steps].
+struct NullOptBufs { float *eps2, *d_eps, *am, *av, *loss_d; };
+static int null_inner_loop(pnpi_ctx* c, const NullOptBufs& b, const float* lat, int t, int i, float* unc, const float* ctx_cond,
+                           const float* target, float guidance_scale, float a_t, float a_p, int num_inner_steps, float epsilon,
+                           int* its_out, float* losses_host) {
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  const float scale = 4096.f;                                   // loss scale of the fp16 activation gradients (removed before Adam)
+  const double sa_t = sqrt((double)a_t), sb_t = sqrt(1.0 - a_t), sa_p = sqrt((double)a_p), sb_p = sqrt(1.0 - a_p);
+  const float c_x = (float)(sa_p / sa_t), c_e = (float)(sb_p - sa_p * sb_t / sa_t);       // rec = c_x x + c_e eps
+  const float lr = (float)(1e-2 * (1.0 - i / 100.0));
+  int its = 0;
+  c->tkv.use = false;
+  int r = unet_fwd(c, lat, 1, t, ctx_cond, false, 0, b.eps2 + E);
+  if (r) return r;
+  CKH(hipMemsetAsync(b.am, 0, CE * sizeof(float), c->st));
+  CKH(hipMemsetAsync(b.av, 0, CE * sizeof(float), c->st));
+  for (int j = 0; j < num_inner_steps; ++j) {
+    // forward with the tape recording; the loss head needs eps_u first, so forward and backward are two calls of the tape machinery
+    Tape& T = *c->tape;
+    T.ops.clear(); T.grads.clear(); T.garena.reset(); T.garena.overflow = false;
+    T.rec = true;
+    r = unet_fwd(c, lat, 1, t, unc, false, 0, b.eps2);
+    T.rec = false;
+    if (r) return r;
+    CK(launch_null_text_loss(b.eps2, b.eps2 + E, lat, target, (int)E, guidance_scale, c_x, c_e, scale, b.d_eps, b.loss_d, c->st));
+    half_t* d_out = tape_galloc(c, (size_t)g.sample_size * g.sample_size * 8);
+    if (!d_out) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+    CK(launch_nchw_f32_to_nhwc_f16(b.d_eps, 1, g.in_channels, g.sample_size * g.sample_size, 8, d_out, c->st));
+    CKH(hipMemsetAsync(T.d_ctx, 0, CE * sizeof(float), c->st));
+    CKP(tape_backward(c, d_out));
+    CK(launch_adam_step(unc, b.am, b.av, T.d_ctx, (int)CE, j + 1, lr, 1.f / scale, c->st));
+    float loss_h = 0.f;
+    CKH(hipMemcpyAsync(&loss_h, b.loss_d, sizeof(float), hipMemcpyDeviceToHost, c->st));
+    CKH(hipStreamSynchronize(c->st));
+    if (losses_host) losses_host[j] = loss_h;
+    its = j + 1;
+    c->ctr.unet_backward_rows += 1;
+    if (loss_h < epsilon + i * 2e-5f) break;
+  }
+  *its_out = its;
+  return 0;
+}
+static int null_bufs(pnpi_ctx* c, NullOptBufs& b) {
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  b.eps2 = misc_f(c, 2 * E); b.d_eps = misc_f(c, E); b.am = misc_f(c, CE); b.av = misc_f(c, CE); b.loss_d = misc_f(c, 1);
+  return 0;
+}
+
 // NullInversion.null_optimization (models/p2p/inversion.py:196-225) for one image, device resident.  ddim_latents [nsteps + 1][E] (the
 // inversion trajectory, x*_0 first), ctx_uncond / ctx_cond [77][768]; uncond_out [nsteps][77][768] receives the optimised embedding of
-// every step.  Per step: eps_c once; up to num_inner_steps x (recording forward with the current embedding, loss + gradient, backward to
-// the embedding, Adam); the loss is read back for the reference's early-stop test; then the CFG step with the optimised embedding.
+// every step; then the CFG step with the optimised embedding moves the latent on.  losses_out (nullable, host): [nsteps][num_inner_steps]
+// loss of every Adam iteration (-1 for iterations the early stop skipped).
 int pnpi_null_text_optimize(pnpi_ctx* c, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,
-                            const int* ts, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out, int* iters_out) {
+                            const int* ts, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out, int* iters_out,
+                            float* losses_out) {
   if (!c || !ddim_latents || !ctx_uncond || !ctx_cond || !ts || !uncond_out || nsteps <= 0 || num_inner_steps < 0) return PNPI_EINVAL;
   CKP(check_ready(c));
   CKP(tape_ensure(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
   const int ratio = g.n_train_timesteps / nsteps;
-  const float scale = 4096.f;                                   // loss scale of the fp16 activation gradients (removed before Adam)
   CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
-  float* eps2 = misc_f(c, 2 * E);                               // [eps_u | eps_c]
-  float* d_eps = misc_f(c, E);
+  NullOptBufs b; null_bufs(c, b);
   float* lat = misc_f(c, E);
   float* unc = misc_f(c, CE);
-  float* am = misc_f(c, CE);
-  float* av = misc_f(c, CE);
-  float* gctx = misc_f(c, CE);
-  float* loss_d = misc_f(c, 1);
   if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  if (losses_out) for (int k = 0; k < nsteps * num_inner_steps; ++k) losses_out[k] = -1.f;
   CKH(hipMemcpyAsync(unc, ctx_uncond, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
   CKH(hipMemcpyAsync(lat, ddim_latents + (size_t)nsteps * E, E * sizeof(float), hipMemcpyDeviceToDevice, c->st));
   for (int i = 0; i < nsteps; ++i) {
     const int t = ts[i];
     float a_t, a_p; CKP(alphas_for(c, t, ratio, false, &a_t, &a_p));
-    const double sa_t = sqrt((double)a_t), sb_t = sqrt(1.0 - a_t), sa_p = sqrt((double)a_p), sb_p = sqrt(1.0 - a_p);
-    const float c_x = (float)(sa_p / sa_t), c_e = (float)(sb_p - sa_p * sb_t / sa_t);       // rec = c_x x + c_e eps
     const float* target = ddim_latents + (size_t)(nsteps - i - 1) * E;
     int its = 0;
-    if (num_inner_steps > 0) {
-      const float lr = (float)(1e-2 * (1.0 - i / 100.0));
-      c->tkv.use = false;
-      int r = unet_fwd(c, lat, 1, t, ctx_cond, false, 0, eps2 + E);
-      if (r) return r;
-      CKH(hipMemsetAsync(am, 0, CE * sizeof(float), c->st));
-      CKH(hipMemsetAsync(av, 0, CE * sizeof(float), c->st));
-      for (int j = 0; j < num_inner_steps; ++j) {
-        // forward with the tape recording; the loss head needs eps_u first, so forward and backward are two calls of the tape machinery
-        Tape& T = *c->tape;
-        T.ops.clear(); T.grads.clear(); T.garena.reset(); T.garena.overflow = false;
-        T.rec = true;
-        r = unet_fwd(c, lat, 1, t, unc, false, 0, eps2);
-        T.rec = false;
-        if (r) return r;
-        CK(launch_null_text_loss(eps2, eps2 + E, lat, target, (int)E, guidance_scale, c_x, c_e, scale, d_eps, loss_d, c->st));
-        half_t* d_out = tape_galloc(c, (size_t)g.sample_size * g.sample_size * 8);
-        if (!d_out) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
-        CK(launch_nchw_f32_to_nhwc_f16(d_eps, 1, g.in_channels, g.sample_size * g.sample_size, 8, d_out, c->st));
-        CKH(hipMemsetAsync(T.d_ctx, 0, CE * sizeof(float), c->st));
-        CKP(tape_backward(c, d_out));
-        CK(launch_adam_step(unc, am, av, T.d_ctx, (int)CE, j + 1, lr, 1.f / scale, c->st));
-        float loss_h = 0.f;
-        CKH(hipMemcpyAsync(&loss_h, loss_d, sizeof(float), hipMemcpyDeviceToHost, c->st));
-        CKH(hipStreamSynchronize(c->st));
-        its = j + 1;
-        if (loss_h < epsilon + i * 2e-5f) break;
-      }
-    }
+    if (num_inner_steps > 0)
+      CKP(null_inner_loop(c, b, lat, t, i, unc, ctx_cond, target, guidance_scale, a_t, a_p, num_inner_steps, epsilon, &its,
+                          losses_out ? losses_out + (size_t)i * num_inner_steps : nullptr));
     if (iters_out) iters_out[i] = its;
     CKH(hipMemcpyAsync(uncond_out + (size_t)i * CE, unc, CE * sizeof(float), hipMemcpyDeviceToDevice, c->st));
     // latent_cur = prev_step(CFG(eps(unc), eps(cond)))   (get_noise_pred with the optimised embedding, inversion.py:221-224)
     c->tkv.use = false;
-    int r = unet_fwd(c, lat, 1, t, unc, false, 0, eps2);
+    int r = unet_fwd(c, lat, 1, t, unc, false, 0, b.eps2);
     if (r) return r;
-    if (num_inner_steps == 0) { r = unet_fwd(c, lat, 1, t, ctx_cond, false, 0, eps2 + E); if (r) return r; }
-    CK(launch_cfg_ddim_prev(eps2, lat, 1, 1, E, guidance_scale, a_t, a_p, nullptr, 0, nullptr, 1.f, nullptr, lat, c->st));
+    if (num_inner_steps == 0) { r = unet_fwd(c, lat, 1, t, ctx_cond, false, 0, b.eps2 + E); if (r) return r; }
+    CK(launch_cfg_ddim_prev(b.eps2, lat, 1, 1, E, guidance_scale, a_t, a_p, nullptr, 0, nullptr, 1.f, nullptr, lat, c->st));
+  }
+  return 0;
+}
+
+// DirectInversion.null_latent_calculate (models/p2p/inversion.py:419-460, "ablation_null-latent-inversion+p2p") for one (source, target)
+// prompt pair.  context4 rows = [unc_src, unc_tgt, cond_src, cond_tgt].  Per step: the unconditional embeddings are optimised as in
+// null-text inversion -- the reference's loss reads the SOURCE row only (:441), so the target row's embedding has a zero gradient, Adam
+// leaves it where it is, and only the source row needs the recording forward / reverse walk; its conditional prediction is constant over
+// the iterations -- then the step's effect becomes a latent offset for both rows:
+//   noise_loss[i] = prev_step(CFG with the optimised embeddings) - prev_step(CFG with the ORIGINAL ones),  latent_cur = plain + noise_loss[i]
+// (:449-459).  The two 4-row forwards run with rows ordered [unc_src, cond_src, unc_tgt, cond_tgt] (row results do not depend on the
+// order) so that the step kernel sees them as two one-row images.  noise_loss_out [nsteps][2][E].
+int pnpi_null_latent_calculate(pnpi_ctx* c, const float* ddim_latents, const float* context4, int nsteps, const int* ts, float guidance_scale,
+                               int num_inner_steps, float epsilon, float* noise_loss_out, int* iters_out, float* losses_out) {
+  if (!c || !ddim_latents || !context4 || !ts || !noise_loss_out || nsteps <= 0 || num_inner_steps < 0) return PNPI_EINVAL;
+  CKP(check_ready(c));
+  if (c->max_rows < 4) return fail(c, PNPI_EINVAL, "null-latent inversion needs max_unet_rows >= 4");
+  CKP(tape_ensure(c));
+  const pnpi_model_config& g = c->cfg;
+  const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
+  const int ratio = g.n_train_timesteps / nsteps;
+  CKP(setup_ctrl(c, nullptr, 0, c->max_rows));
+  NullOptBufs b; null_bufs(c, b);
+  float* cur = misc_f(c, 2 * E);          // latent_cur [src, tgt]
+  float* in4 = misc_f(c, 4 * E);          // [src, src, tgt, tgt]
+  float* eps4 = misc_f(c, 4 * E);
+  float* opt = misc_f(c, 2 * E);
+  float* unc = misc_f(c, 2 * CE);         // the embeddings being optimised [src, tgt] (warm-started from step to step)
+  float* ctx4 = misc_f(c, 4 * CE);        // [unc_src, cond_src, unc_tgt, cond_tgt] of the forward at hand
+  if (c->ctrl_arena.overflow) return fail(c, PNPI_ENOMEM, "loop arena overflow");
+  if (losses_out) for (int k = 0; k < nsteps * num_inner_steps; ++k) losses_out[k] = -1.f;
+  const float* cond = context4 + 2 * CE;
+  auto d2d = [&](float* d, const float* s, size_t n) { return hipMemcpyAsync(d, s, n * sizeof(float), hipMemcpyDeviceToDevice, c->st); };
+  CKH(d2d(unc, context4, 2 * CE));
+  CKH(d2d(cur, ddim_latents + (size_t)nsteps * E, E));
+  CKH(d2d(cur + E, ddim_latents + (size_t)nsteps * E, E));
+  CKH(d2d(ctx4 + CE, cond, CE));
+  CKH(d2d(ctx4 + 3 * CE, cond + CE, CE));
+  for (int i = 0; i < nsteps; ++i) {
+    const int t = ts[i];
+    float a_t, a_p; CKP(alphas_for(c, t, ratio, false, &a_t, &a_p));
+    const float* target = ddim_latents + (size_t)(nsteps - i - 1) * E;
+    int its = 0;
+    if (num_inner_steps > 0)
+      CKP(null_inner_loop(c, b, cur, t, i, unc, cond, target, guidance_scale, a_t, a_p, num_inner_steps, epsilon, &its,
+                          losses_out ? losses_out + (size_t)i * num_inner_steps : nullptr));
+    if (iters_out) iters_out[i] = its;
+    CKH(d2d(in4, cur, E)); CKH(d2d(in4 + E, cur, E)); CKH(d2d(in4 + 2 * E, cur + E, E)); CKH(d2d(in4 + 3 * E, cur + E, E));
+    c->tkv.use = false;
+    // with the optimised embeddings -> opt
+    CKH(d2d(ctx4, unc, CE)); CKH(d2d(ctx4 + 2 * CE, unc + CE, CE));
+    int r = unet_fwd(c, in4, 4, t, ctx4, false, 0, eps4);
+    if (r) return r;
+    CK(launch_cfg_ddim_prev(eps4, cur, 2, 1, E, guidance_scale, a_t, a_p, nullptr, 0, nullptr, 1.f, nullptr, opt, c->st));
+    // with the original ones -> plain; loss = opt - plain; latent_cur = plain + loss
+    CKH(d2d(ctx4, context4, CE)); CKH(d2d(ctx4 + 2 * CE, context4 + CE, CE));
+    r = unet_fwd(c, in4, 4, t, ctx4, false, 0, eps4);
+    if (r) return r;
+    CK(launch_cfg_ddim_prev(eps4, cur, 2, 1, E, guidance_scale, a_t, a_p, nullptr, 0, opt, 1.f, noise_loss_out + (size_t)i * 2 * E, cur, c->st));
   }
   return 0;
 }

@@ -268,6 +268,24 @@ int launch_strided_add_f16(half_t* dst, const half_t* src, int ld, int off, size
   strided_add_f16_kernel<<<blocks, 256, 0, st>>>(dst, src, ld, off, R, C, accumulate);
   return (int)hipGetLastError();
 }
+// [R][heads * dh] -> [R][heads * Dp] with zero pad columns (attention backward of head widths that are not a multiple of 8: the reduced
+// test configurations; every SD-1.x head width is)
+__global__ void __launch_bounds__(256) pad_heads_f16_kernel(const half_t* __restrict__ src, size_t R, int heads, int dh, int Dp, half_t* __restrict__ dst) {
+  const size_t total = R * heads * Dp;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % Dp);
+    const size_t rh = idx / Dp;
+    const int h = (int)(rh % heads);
+    const size_t r = rh / heads;
+    dst[idx] = d < dh ? src[(r * heads + h) * dh + d] : (half_t)0.f;
+  }
+}
+int launch_pad_heads_f16(const half_t* src, size_t R, int heads, int dh, int Dp, half_t* dst, hipStream_t st) {
+  const size_t total = R * heads * Dp;
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  pad_heads_f16_kernel<<<blocks, 256, 0, st>>>(src, R, heads, dh, Dp, dst);
+  return (int)hipGetLastError();
+}
 // dst (fp32) += scale * src (fp16): the context gradient is summed over the 16 cross-attention layers in fp32
 __global__ void __launch_bounds__(256) add_f16_to_f32_kernel(float* __restrict__ dst, const half_t* __restrict__ src, size_t n, float scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += scale * (float)src[i];

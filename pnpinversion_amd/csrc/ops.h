@@ -149,4 +149,5 @@ int launch_add_f16_to_f32(float* dst, const half_t* src, size_t n, float scale, 
 int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x, const float* target, int n, float w, float c_x, float c_e,
                           float grad_scale, float* d_eps_u, float* loss, hipStream_t st);
 int launch_adam_step(float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale, hipStream_t st);
+int launch_pad_heads_f16(const half_t* src, size_t R, int heads, int dh, int Dp, half_t* dst, hipStream_t st);
 int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st);

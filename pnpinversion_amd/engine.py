@@ -357,17 +357,40 @@ class NativeEngine:
         self._call("pnpi_unet_context_grad", _p(lat), int(t), _p(ctx), _p(de), _p(eps), _p(dctx))
         return eps, dctx
 
-    def null_text_optimize(self, ddim_latents, ctx_uncond, ctx_cond, timesteps, guidance_scale, num_inner_steps=10, epsilon=1e-5):
-        """NullInversion.null_optimization for one image -> ([steps, 1, 77, D] embeddings, [steps] Adam iterations run)."""
+    def null_text_optimize(self, ddim_latents, ctx_uncond, ctx_cond, timesteps, guidance_scale, num_inner_steps=10, epsilon=1e-5,
+                           return_losses=False):
+        """NullInversion.null_optimization for one image -> ([steps, 1, 77, D] embeddings, [steps] Adam iterations run[, per-step lists
+        of every iteration's loss])."""
         lat = self._f32(ddim_latents)
         n = lat.shape[0] - 1
         cu, cc = self._f32(ctx_uncond), self._f32(ctx_cond)
         out = torch.empty(n, 1, cu.shape[-2], cu.shape[-1], device=self.device, dtype=torch.float32)
         its = (C.c_int * n)()
+        losses = (C.c_float * max(1, n * int(num_inner_steps)))()
         ts_keep, ts_ptr = self._ts(timesteps)
         self._call("pnpi_null_text_optimize", _p(lat), _p(cu), _p(cc), n, ts_ptr, float(guidance_scale), int(num_inner_steps),
-                   float(epsilon), _p(out), its)
+                   float(epsilon), _p(out), its, losses)
         del ts_keep
+        if return_losses:
+            return out, list(its), [[losses[i * num_inner_steps + j] for j in range(its[i])] for i in range(n)]
+        return out, list(its)
+
+    def null_latent_calculate(self, ddim_latents, context4, timesteps, guidance_scale, num_inner_steps=10, epsilon=1e-5, return_losses=False):
+        """DirectInversion.null_latent_calculate for one prompt pair -> [steps, 2, 4, h, w] latent offsets (context4 rows:
+        unc_src, unc_tgt, cond_src, cond_tgt)."""
+        lat = self._f32(ddim_latents)
+        n = lat.shape[0] - 1
+        c4 = self._f32(context4)
+        assert c4.shape[0] == 4, "null_latent_calculate handles one (source, target) prompt pair"
+        out = torch.empty(n, 2, *lat.shape[-3:], device=self.device, dtype=torch.float32)
+        its = (C.c_int * n)()
+        losses = (C.c_float * max(1, n * int(num_inner_steps)))()
+        ts_keep, ts_ptr = self._ts(timesteps)
+        self._call("pnpi_null_latent_calculate", _p(lat), _p(c4), n, ts_ptr, float(guidance_scale), int(num_inner_steps), float(epsilon),
+                   _p(out), its, losses)
+        del ts_keep
+        if return_losses:
+            return out, list(its), [[losses[i * num_inner_steps + j] for j in range(its[i])] for i in range(n)]
         return out, list(its)
 
     def ddim_invert(self, z0, ctx_cond, timesteps):

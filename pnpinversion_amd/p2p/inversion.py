@@ -127,8 +127,23 @@ class DirectInversion:
         noise_loss_list = self.offset_calculate_skip_step(ddim_latents, num_inner_steps, early_stop_epsilon, guidance_scale, skip_step)
         return image_gt, image_rec, ddim_latents, noise_loss_list
 
-    def invert_null_latent(self, *a, **k):
-        raise NotImplementedError("null-latent inversion optimises through the UNet (backward pass): not built (SURVEY 8f rank 4)")
+    def null_latent_calculate(self, latents, num_inner_steps, epsilon, guidance_scale):
+        """inversion.py:419-460 -> list of num_ddim_steps tensors [2,4,h,w]: the device loop pnpi_null_latent_calculate (per step the
+        null-text optimisation of the source row's unconditional embedding, then the step's effect as a latent offset)."""
+        if self.context.shape[0] != 4:
+            raise NotImplementedError("null_latent_calculate handles one (source, target) prompt pair")
+        nl, self.inner_iterations, self.inner_losses = self._engine.null_latent_calculate(
+            torch.stack(list(latents)), self.context, self.scheduler.timesteps.numpy(), guidance_scale, num_inner_steps, epsilon,
+            return_losses=True)
+        return [nl[i] for i in range(nl.shape[0])]
+
+    def invert_null_latent(self, image_gt, prompt, guidance_scale, num_inner_steps=10, early_stop_epsilon=1e-5):
+        """inversion.py:462-470"""
+        self.init_prompt(prompt)
+        register_attention_control(self.model, None)
+        image_rec, ddim_latents = self.ddim_inversion(image_gt)
+        latent_list = self.null_latent_calculate(ddim_latents, num_inner_steps, early_stop_epsilon, guidance_scale)
+        return image_gt, image_rec, ddim_latents, latent_list
 
     def invert_without_attn_controller(self, image_gt, prompt, guidance_scale, num_inner_steps=10, early_stop_epsilon=1e-5):
         self.init_prompt(prompt)
@@ -193,8 +208,9 @@ class NullInversion(_SinglePromptInversion):
             # the embedding never changes; the reference also walks latent_cur down a 50-step CFG loop whose result nobody reads
             # (inversion.py:228-230) -- not executed here
             return [uncond[:1]] * self.num_ddim_steps
-        embs, self.inner_iterations = self.model.engine.null_text_optimize(torch.stack(list(latents)), uncond, cond, self.scheduler.timesteps.numpy(),
-                                                                           guidance_scale, num_inner_steps, epsilon)
+        embs, self.inner_iterations, self.inner_losses = self.model.engine.null_text_optimize(
+            torch.stack(list(latents)), uncond, cond, self.scheduler.timesteps.numpy(), guidance_scale, num_inner_steps, epsilon,
+            return_losses=True)
         return [embs[i] for i in range(embs.shape[0])]
 
     def invert(self, image_gt, prompt, guidance_scale, num_inner_steps=10, early_stop_epsilon=1e-5):

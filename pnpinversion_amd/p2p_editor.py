@@ -5,8 +5,8 @@ every loop variant of it that needs no new kernel -- "ddim+p2p", "negative-promp
 "directinversion+p2p_guidance_<inv>_<fwd>" strings, "ablation_directinversion_{04,08}+p2p",
 "ablation_directinversion_interval_{2,5,10,24,49}+p2p", "ablation_directinversion_add-target+p2p" / "...add-source+p2p".
 "null-text-inversion+p2p" (and its two aliases), "ablation_null-text-inversion_single_branch+p2p" and
-"null-text-inversion+proximal-guidance" run the device null-text optimisation (pnpi_null_text_optimize); the null-latent variant
-raises NotImplementedError naming what is missing; any other string raises the reference's
+"null-text-inversion+proximal-guidance" run the device null-text optimisation (pnpi_null_text_optimize),
+"ablation_null-latent-inversion+p2p" its latent-offset variant (pnpi_null_latent_calculate); any other string raises the reference's
 NotImplementedError(f"No edit method named {edit_method}") (models/p2p_editor.py:134-135)."""
 import numpy as np
 from PIL import Image
@@ -113,7 +113,8 @@ class P2PEditor:
 
     def edit_image_directinversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
                                    self_replace_steps=0.6, blend_word=None, eq_params=None, is_replace_controller=False,
-                                   add_target=False, return_stages=False, inverse_guidance_scale=None, offset_scale=None):
+                                   add_target=False, return_stages=False, inverse_guidance_scale=None, offset_scale=None,
+                                   null_latent=False):
         """models/p2p_editor.py:415-479; with the keyword-only knobs also :481-548 (vary guidance: CFG inversion at
         inverse_guidance_scale, everything else at guidance_scale), :707-773 (not_full: offset_scale = scale) and :775-840
         (skip_step: offset_scale = per-step 0/1 list)."""
@@ -126,17 +127,22 @@ class P2PEditor:
         null_inversion = DirectInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
         if self.schedule not in ("faithful", "pruned"):
             raise ValueError("P2PEditor.schedule must be 'faithful' or 'pruned'")
-        if (self.lockstep and self.ldm_stable.engine.max_unet_rows >= 12) or self.schedule == "pruned":
+        if null_latent:
+            # models/p2p_editor.py:640-705: the offsets come from DirectInversion.invert_null_latent (an optimisation through the UNet per
+            # step), the two guidance passes are the direct-inversion ones; phase order of the reference (nothing to run in lock step)
+            _, _, x_stars, noise_loss_list = null_inversion.invert_null_latent(image_gt=image_gt, prompt=prompts, guidance_scale=guidance_scale)
+        elif (self.lockstep and self.ldm_stable.engine.max_unet_rows >= 12) or self.schedule == "pruned":
             return self._edit_lockstep(null_inversion, image_gt, prompts, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                                        self_replace_steps, blend_word, eq_params, is_replace_controller, add_target, return_stages, side,
                                        inverse_guidance_scale, offset_scale)
-        null_inversion.init_prompt(prompts)
-        register_attention_control(self.ldm_stable, None)
-        if inverse_guidance_scale is None:
-            _, x_stars = null_inversion.ddim_inversion(image_gt)
-        else:
-            _, x_stars = null_inversion.ddim_with_guidance_scale_inversion(image_gt, inverse_guidance_scale)
-        noise_loss_list = null_inversion._offsets(x_stars, guidance_scale, offset_scale)
+        if not null_latent:
+            null_inversion.init_prompt(prompts)
+            register_attention_control(self.ldm_stable, None)
+            if inverse_guidance_scale is None:
+                _, x_stars = null_inversion.ddim_inversion(image_gt)
+            else:
+                _, x_stars = null_inversion.ddim_with_guidance_scale_inversion(image_gt, inverse_guidance_scale)
+            noise_loss_list = null_inversion._offsets(x_stars, guidance_scale, offset_scale)
         x_t = x_stars[-1]
         controller = AttentionStore()
         reconstruct_latent, x_t = forward(model=self.ldm_stable, prompt=prompts, controller=controller, noise_loss_list=noise_loss_list,
@@ -247,6 +253,7 @@ class P2PEditor:
                               self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
         if return_stages:
             out[1]["uncond_embeddings"] = uncond_embeddings
+            out[1]["inner_losses"] = getattr(inv, "inner_losses", None)
         return out
 
     def edit_image_null_text_inversion_single_branch(self, image_path, prompt_src, prompt_tar, **kw):
@@ -262,9 +269,8 @@ class P2PEditor:
                                                    use_reconstruction_guidance=use_reconstruction_guidance, **kw)
 
     def edit_image_null_latent_inversion(self, image_path, prompt_src, prompt_tar, **kw):
-        """models/p2p_editor.py:640-705"""
-        raise NotImplementedError("ablation_null-latent-inversion+p2p: the two-prompt latent-offset variant of the null-text optimisation is "
-                                  "not built (DirectInversion.null_latent_calculate, inversion.py:418-460)")
+        """models/p2p_editor.py:640-705: DirectInversion.invert_null_latent (pnpi_null_latent_calculate) + the two direct-inversion passes"""
+        return self.edit_image_directinversion(image_path, prompt_src, prompt_tar, null_latent=True, **kw)
 
     def edit_image_negative_prompt_inversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, proximal=None,
                                              quantile=0.7, use_reconstruction_guidance=False, recon_t=400, recon_lr=0.1, npi_interp=0,

