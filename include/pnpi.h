@@ -189,6 +189,11 @@ int pnpi_latent2image(pnpi_ctx* ctx, const float* z_nchw, int n, int lat_h, int 
 int pnpi_ddim_next_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, const float* sample, size_t n, float* out);
 /* DirectInversion.prev_step (inversion.py:247-260) == DDIMSchedulerDev.step (scheduler_dev.py:38-95), eta = 0 */
 int pnpi_ddim_prev_step(pnpi_ctx* ctx, const float* eps, int t, int step_ratio, const float* sample, size_t n, float* out);
+/* DDIMSchedulerDev.step with the reconstruction pull          models/p2p/scheduler_dev.py:68-76
+ * (kwargs ref_image / recon_lr / recon_mask): pred_x0 -= recon_lr * (pred_x0 - ref_image) [* recon_mask] between the step's two halves.
+ * ref_image / recon_mask are device fp32 arrays of the sample's shape (the caller expands them), recon_mask and pred_x0_out nullable. */
+int pnpi_ddim_prev_step_recon(pnpi_ctx* ctx, const float* eps, int t, int ratio, const float* sample, size_t n, const float* ref_image,
+                              float recon_lr, const float* recon_mask, float* out, float* pred_x0_out);
 /* fused CFG + prev_step + direct-inversion offset (inversion.py:383-389; p2p_guidance_forward.py:110-114).
  *   eps [nimg][2R][E]; x [nimg][R][E]; target (nullable) [nimg][E] -> offset_out = (target - prev) * offset_scale (1 on
  *   the paper's path; the not_full / skip_step ablations scale or zero it, inversion.py:491-492,512-515), x_out = prev + offset;

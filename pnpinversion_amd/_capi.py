@@ -85,6 +85,7 @@ SYMBOLS = {
     "pnpi_latent2image": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pnpi_ddim_next_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "pnpi_ddim_prev_step": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "pnpi_ddim_prev_step_recon": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp, _f, _vp, _vp, _vp]),
     "pnpi_cfg_ddim_prev": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, C.POINTER(ReconDesc)]),
     "pnpi_prox_threshold": (_i, [_vp, _vp, _i, _i, _sz, _f, _vp]),
     "pnpi_text_encode": (_i, [_vp, _vp, _i, _vp]),

@@ -356,6 +356,8 @@ struct Tape {
   void* attn_scratch = nullptr; size_t attn_scratch_bytes = 0;
 };
 static inline bool taping(pnpi_ctx* c) { return c->tape && c->tape->rec && !c->dry; }
+// a recording forward (or the dry run that sizes the arenas for one) keeps every activation and takes the plain-layout transformer block
+static inline bool keep_acts(pnpi_ctx* c) { return c->tape && c->tape->rec; }
 
 // ---------------------------------------------------------------------------------------------------- op wrappers
 // Per-channel GroupNorm partial sums attached to an activation by the GEMM that produced it ([tiles][C][2], `rows` per tile).
@@ -472,7 +474,7 @@ static int resnet_fwd(pnpi_ctx* c, const ResnetW& r, const half_t* x1, int C1, c
   }
   CK(op_conv(c, t3, r.cout, nullptr, 0, B, H, W, r.c2, 1, 1, 0, r.c2.b, sc, out, H, W, -1, nullptr, &q2));
   if (so) { so->p = q2.buf; so->rows = q2.rows; }
-  if (!taping(c)) c->temp.release(mk);      // a recording forward keeps every activation for the backward pass
+  if (!keep_acts(c)) c->temp.release(mk);      // a recording forward keeps every activation for the backward pass
   return 0;
 }
 
@@ -761,7 +763,7 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
       h = o; ch = oc; hs_ = ns;
       if (g.block_has_attn[i]) {
         half_t* o2 = palloc(c, (size_t)B * H * H * oc);
-        if (taping(c)) { CKP(transformer_fwd_tape(c, u.down_attn[i][j], h, B, H, H, ctx16, o2)); ns = Stats(); }
+        if (keep_acts(c)) { CKP(transformer_fwd_tape(c, u.down_attn[i][j], h, B, H, H, ctx16, o2)); ns = Stats(); }
         else CKP(transformer_fwd(c, u.down_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
         h = o2; hs_ = ns;
       }
@@ -781,7 +783,7 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
     Stats n1, n2, n3;
     CKP(resnet_fwd(c, u.mid_res[0], h, ch, nullptr, 0, B, H, H, G, eps, o, hs_, Stats(), &n1));
     half_t* o2 = palloc(c, (size_t)B * H * H * ch);
-    if (taping(c)) { CKP(transformer_fwd_tape(c, u.mid_attn, o, B, H, H, ctx16, o2)); n2 = Stats(); }
+    if (keep_acts(c)) { CKP(transformer_fwd_tape(c, u.mid_attn, o, B, H, H, ctx16, o2)); n2 = Stats(); }
     else CKP(transformer_fwd(c, u.mid_attn, o, B, H, H, ctx16, use_ctrl, cur_step, o2, n1, &n2));
     half_t* o3 = palloc(c, (size_t)B * H * H * ch);
     CKP(resnet_fwd(c, u.mid_res[1], o2, ch, nullptr, 0, B, H, H, G, eps, o3, n2, Stats(), &n3));
@@ -797,7 +799,7 @@ static int unet_fwd(pnpi_ctx* c, const float* latents, int rows, int t, const fl
       h = o; ch = oc; hs_ = ns;
       if (g.block_has_attn[n - 1 - i]) {
         half_t* o2 = palloc(c, (size_t)B * H * H * oc);
-        if (taping(c)) { CKP(transformer_fwd_tape(c, u.up_attn[i][j], h, B, H, H, ctx16, o2)); ns = Stats(); }
+        if (keep_acts(c)) { CKP(transformer_fwd_tape(c, u.up_attn[i][j], h, B, H, H, ctx16, o2)); ns = Stats(); }
         else CKP(transformer_fwd(c, u.up_attn[i][j], h, B, H, H, ctx16, use_ctrl, cur_step, o2, hs_, &ns));
         h = o2; hs_ = ns;
       }
@@ -1631,6 +1633,14 @@ static int check_ready(pnpi_ctx* c) {   // UNet / VAE entry points: the text enc
     if (!kv.second.loaded && !is_clip_slot(kv.first)) { c->err = "weights not loaded: " + kv.first; return PNPI_ESTATE; }
   return 0;
 }
+// Level-2 entry points (whole loops in one call): they drive unet_fwd directly with kernel descriptors, so a host attention callback
+// left installed by an earlier level-1 forward would silently replace the descriptor edits (and run during inversion).  Fail loudly.
+static int check_loop_ready(pnpi_ctx* c) {
+  CKP(check_ready(c));
+  if (c->attn_cb) return fail(c, PNPI_ESTATE, "an attention callback is installed (pnpi_set_attention_callback): the loop entry points take kernel "
+                                               "descriptors only -- remove the callback first (callback controllers run through pnpi_unet_forward)");
+  return 0;
+}
 static int check_clip_ready(pnpi_ctx* c) {
   if (c->clip.layers.empty()) return fail(c, PNPI_ESTATE, "this context was built without a text encoder (clip_layers = 0)");
   for (auto& kv : c->slots)
@@ -1759,6 +1769,16 @@ int pnpi_ddim_prev_step(pnpi_ctx* c, const float* eps, int t, int ratio, const f
   CK(launch_ddim_move(sample, eps, af, at, n, out, c->st));
   return 0;
 }
+// DDIMSchedulerDev.step(model_output, t, sample, ref_image=, recon_lr=, recon_mask=) (scheduler_dev.py:38-95 with :68-76): one launch.
+// ref / mask (nullable) are full-shape like the sample; pred_x0_out nullable.
+int pnpi_ddim_prev_step_recon(pnpi_ctx* c, const float* eps, int t, int ratio, const float* sample, size_t n, const float* ref_image,
+                              float recon_lr, const float* recon_mask, float* out, float* pred_x0_out) {
+  if (!c || !eps || !sample || !out) return PNPI_EINVAL;
+  float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
+  const bool on = ref_image && recon_lr > 0.f;
+  CK(launch_ddim_prev_recon(sample, eps, af, at, on ? ref_image : nullptr, recon_lr, on ? recon_mask : nullptr, n, out, pred_x0_out, c->st));
+  return 0;
+}
 static bool recon_active(const pnpi_recon_desc* rc, int t) {   // proximal_guidance_forward.py:48,60
   return rc && rc->ref_image && rc->recon_lr > 0.f && ((rc->recon_t > 0 && t < rc->recon_t) || (rc->recon_t < 0 && t > -rc->recon_t));
 }
@@ -1854,7 +1874,7 @@ struct LoopKV {
 };
 int pnpi_ddim_invert(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_cond, int nsteps, const int* ts, float* all) {
   if (!c || !z0 || !ctx_cond || !ts || !all || nsteps <= 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
   const int ratio = g.n_train_timesteps / nsteps;
@@ -1881,7 +1901,7 @@ static int upload_ints(pnpi_ctx* c, const std::vector<int>& v, int** dst);
 int pnpi_ddim_invert_cfg(pnpi_ctx* c, const float* z0, int nimg, const float* ctx_uncond, const float* ctx_cond, float gs, int nsteps,
                          const int* ts, float* all) {
   if (!c || !z0 || !ctx_uncond || !ctx_cond || !ts || !all || nsteps <= 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
   const int ratio = g.n_train_timesteps / nsteps, rows = 2 * nimg;
@@ -1923,7 +1943,7 @@ static int upload_ints(pnpi_ctx* c, const std::vector<int>& v, int** dst) {
 int pnpi_offset_calculate(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, int nsteps, const int* ts, float gs,
                           const float* offset_scale_host, float* noise_loss_out) {
   if (!c || !lat_all || !context4 || !ts || !noise_loss_out || nsteps <= 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
   const int ratio = g.n_train_timesteps / nsteps, rows = 4 * nimg;
@@ -1960,7 +1980,7 @@ static int edit_loop_impl(pnpi_ctx* c, const float* x_T, int nimg, const float* 
                           const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
                           const pnpi_recon_desc* recon, float* latents_out, const float* uncond_steps, int uncond_first_only) {
   if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
   const int ratio = g.n_train_timesteps / nsteps, rows = 4 * nimg;
@@ -2036,7 +2056,7 @@ int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* c
                      int offset_rows, int nsteps, const int* ts, float gs, const float* offset_scale_host, float* noise_loss_out,
                      float* latents_out) {
   if (!c || !lat_all || !context4 || !ts || !noise_loss_out || !latents_out || nsteps <= 0 || npass <= 0 || nimg <= 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
   const size_t CE = (size_t)g.ctx_len * g.cross_dim;
@@ -2093,7 +2113,7 @@ int pnpi_direct_edit(pnpi_ctx* c, const float* lat_all, int nimg, const float* c
 int pnpi_direct_edit_pruned(pnpi_ctx* c, const float* lat_all, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host,
                             int nsteps, const int* ts, float gs, float* latents_out) {
   if (!c || !lat_all || !context4 || !ts || !latents_out || nsteps <= 0 || nimg <= 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
   const int ratio = g.n_train_timesteps / nsteps, rows = 3 * nimg;
@@ -2225,13 +2245,31 @@ static int tape_ensure(pnpi_ctx* c) {
   CKH(hipMalloc((void**)&T->garena.base, T->garena.cap));
   CKH(hipMalloc((void**)&T->d_ctx, (size_t)g.ctx_len * g.cross_dim * sizeof(float)));
   c->tape = T;
+  // The activation arenas were sized at create for max_unet_rows rows of the plain forward (block temporaries released in stack order).
+  // A recording forward of ONE row keeps every temporary: measure it with a dry run and grow the arenas if that is more (set-up time
+  // only -- nothing is allocated in the optimisation loop).
+  {
+    CKH(hipStreamSynchronize(c->st));
+    const Bump sp = c->persist, stmp = c->temp;
+    c->persist = Bump(); c->temp = Bump();
+    c->dry = true; T->rec = true;
+    const bool kv = c->tkv.use; c->tkv.use = false;
+    const int r = unet_fwd(c, nullptr, 1, 0, nullptr, false, 0, nullptr);
+    c->dry = false; T->rec = false; c->tkv.use = kv;
+    const size_t pp = align_up(c->persist.peak + (1 << 20), 4096), tp = align_up(c->temp.peak + (1 << 20), 4096);
+    c->persist = sp; c->temp = stmp;
+    if (r) return r;
+    if (pp > c->persist.cap) { CKH(hipFree(c->persist.base)); c->persist.base = nullptr; CKH(hipMalloc((void**)&c->persist.base, pp)); c->persist.cap = pp; }
+    if (tp > c->temp.cap) { CKH(hipFree(c->temp.base)); c->temp.base = nullptr; CKH(hipMalloc((void**)&c->temp.base, tp)); c->temp.cap = tp; }
+    c->persist.reset(); c->temp.reset(); c->persist.overflow = false; c->temp.overflow = false;
+  }
   return 0;
 }
 // eps = UNet(latents, t, context) for ONE row, and d_context = (d loss / d eps)^T (d eps / d context) for the given d loss / d eps
 // (fp32, the layout of eps; pre-multiplied by the caller's power-of-two loss scale -- activations' gradients travel in fp16).
 int pnpi_unet_context_grad(pnpi_ctx* c, const float* latents, int t, const float* context, const float* d_eps, float* eps_out, float* d_context_out) {
   if (!c || !latents || !context || !d_eps || !d_context_out) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   CKP(tape_ensure(c));
   Tape& T = *c->tape;
   const pnpi_model_config& g = c->cfg;
@@ -2314,7 +2352,7 @@ int pnpi_null_text_optimize(pnpi_ctx* c, const float* ddim_latents, const float*
                             const int* ts, float guidance_scale, int num_inner_steps, float epsilon, float* uncond_out, int* iters_out,
                             float* losses_out) {
   if (!c || !ddim_latents || !ctx_uncond || !ctx_cond || !ts || !uncond_out || nsteps <= 0 || num_inner_steps < 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   CKP(tape_ensure(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size, CE = (size_t)g.ctx_len * g.cross_dim;
@@ -2358,7 +2396,7 @@ int pnpi_null_text_optimize(pnpi_ctx* c, const float* ddim_latents, const float*
 int pnpi_null_latent_calculate(pnpi_ctx* c, const float* ddim_latents, const float* context4, int nsteps, const int* ts, float guidance_scale,
                                int num_inner_steps, float epsilon, float* noise_loss_out, int* iters_out, float* losses_out) {
   if (!c || !ddim_latents || !context4 || !ts || !noise_loss_out || nsteps <= 0 || num_inner_steps < 0) return PNPI_EINVAL;
-  CKP(check_ready(c));
+  CKP(check_loop_ready(c));
   if (c->max_rows < 4) return fail(c, PNPI_EINVAL, "null-latent inversion needs max_unet_rows >= 4");
   CKP(tape_ensure(c));
   const pnpi_model_config& g = c->cfg;

@@ -121,6 +121,8 @@ int launch_attn_cross_edit(const CrossEditP& p, hipStream_t st);
 // x_next = sqrt(a_next) * ((x - sqrt(1-a_t) * eps) / sqrt(a_t)) + sqrt(1-a_next) * eps
 int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to, size_t n, float* out, hipStream_t st);
 // Classifier-free guidance + DDIM denoise step (+ direct-inversion offset). See include/pnpi.h pnpi_cfg_ddim_prev.
+int launch_ddim_prev_recon(const float* x, const float* eps, float a_from, float a_to, const float* ref, float lr, const float* mask, size_t n,
+                           float* out, float* x0_out, hipStream_t st);
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale,
                          float a_t, float a_prev, const float* noise_loss, int offset_rows, const float* target,
                          float offset_scale, float* offset_out, float* x_out, hipStream_t st, const float* prox_thr = nullptr,

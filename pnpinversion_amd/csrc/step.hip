@@ -37,6 +37,34 @@ int launch_ddim_move(const float* x, const float* eps, float a_from, float a_to,
   return (int)hipGetLastError();
 }
 
+// DDIMSchedulerDev.step with the reconstruction pull (scheduler_dev.py:68-76), level-1 form: ref / mask already expanded to the sample's
+// shape.  pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  pred_x0 -= lr * (pred_x0 - ref) [* mask];  prev = sqrt(a_p) pred_x0 + sqrt(1-a_p) e.
+// pred_x0_out (nullable) receives the pulled pred_original_sample (the reference returns it).
+__global__ void ddim_prev_recon_kernel(const float* __restrict__ x, const float* __restrict__ eps, float sa_f, float sb_f, float sa_t, float sb_t,
+                                       const float* __restrict__ ref, float lr, const float* __restrict__ mask, size_t n,
+                                       float* __restrict__ out, float* __restrict__ x0_out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float e = eps[i];
+    float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(sb_f, e)), sa_f);
+    if (ref) {
+      float pull = __fmul_rn(lr, __fsub_rn(x0, ref[i]));
+      if (mask) pull = __fmul_rn(pull, mask[i]);
+      x0 = __fsub_rn(x0, pull);
+    }
+    if (x0_out) x0_out[i] = x0;
+    out[i] = __fadd_rn(__fmul_rn(sa_t, x0), __fmul_rn(sb_t, e));
+  }
+}
+int launch_ddim_prev_recon(const float* x, const float* eps, float a_from, float a_to, const float* ref, float lr, const float* mask, size_t n,
+                           float* out, float* x0_out, hipStream_t st) {
+  float sa_f = sqrtf(a_from), sb_f = sqrtf(1.0f - a_from), sa_t = sqrtf(a_to), sb_t = sqrtf(1.0f - a_to);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  ddim_prev_recon_kernel<<<blocks, 256, 0, st>>>(x, eps, sa_f, sb_f, sa_t, sb_t, ref, lr, mask, n, out, x0_out);
+  return (int)hipGetLastError();
+}
+
 // proximal guidance (proximal_guidance_forward.py:39-62): score_delta -= clamp(score_delta, -thr, thr); 'l1' then shrinks the
 // survivors by thr once more on each side
 __device__ __forceinline__ float prox_shrink(float d, float th, int mode) {

@@ -332,6 +332,17 @@ class NativeEngine:
         self._keep = (e, s)
         return out
 
+    def ddim_prev_step_recon(self, eps, t, ratio, sample, ref_image, recon_lr, recon_mask=None):
+        """DDIMSchedulerDev.step with ref_image / recon_lr / recon_mask (scheduler_dev.py:68-76) -> (prev_sample, pred_original_sample)"""
+        e, s = self._f32(eps), self._f32(sample)
+        ref = self._f32(ref_image.to(self.device).expand_as(s))
+        mask = None if recon_mask is None else self._f32(recon_mask.to(self.device).expand_as(s).float())
+        out, x0 = torch.empty_like(s), torch.empty_like(s)
+        self._call("pnpi_ddim_prev_step_recon", _p(e), int(t), int(ratio), _p(s), s.numel(), _p(ref), float(recon_lr),
+                   _p(mask) if mask is not None else None, _p(out), _p(x0))
+        self._keep = (e, s, ref, mask)
+        return out, x0
+
     # ---- level 2
     def _ts(self, timesteps):
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int32))

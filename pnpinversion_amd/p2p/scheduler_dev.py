@@ -55,10 +55,13 @@ class DDIMSchedulerDev:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         if eta > 0 or use_clipped_model_output or kwargs.get("clip_sample", False) or self.config.prediction_type != "epsilon":
             raise NotImplementedError("the native scheduler step implements eta = 0 / epsilon prediction / no clipping")
-        if kwargs.get("ref_image", None) is not None and kwargs.get("recon_lr", 0.0) > 0.0:
-            raise NotImplementedError("proximal-guidance reconstruction pull (scheduler_dev.py:68-76) is a 'next' row (SURVEY 8f-3)")
         if self._engine is None:
             raise RuntimeError("scheduler is not bound to a NativeEngine")
+        if kwargs.get("ref_image", None) is not None and kwargs.get("recon_lr", 0.0) > 0.0:
+            # scheduler_dev.py:68-76: pred_x0 -= recon_lr * (pred_x0 - ref_image) [* recon_mask], one fused launch
+            prev, x0 = self._engine.ddim_prev_step_recon(model_output, int(timestep), self.step_ratio, sample, kwargs["ref_image"],
+                                                         kwargs["recon_lr"], kwargs.get("recon_mask", None))
+            return DDIMSchedulerOutput(prev_sample=prev, pred_original_sample=x0) if return_dict else (prev,)
         prev = self._engine.ddim_prev_step(model_output, int(timestep), self.step_ratio, sample)
         if not return_dict:
             return (prev,)

@@ -46,9 +46,66 @@ class NativeVAE:
         return torch.cat([self.engine.image2latent(image[i:i + m]) for i in range(0, image.shape[0], m)])
 
 
+class _NotExecuted:
+    """to_q / to_k / to_v / to_out of an attention-site marker: the projections run inside libpnpi, never through Python."""
+
+    def __call__(self, *a, **k):
+        raise RuntimeError("the native UNet executes its attention sites inside libpnpi; this marker only lets "
+                           "register_attention_control find and hook the site")
+
+
+class CrossAttention:
+    """Marker object for ONE of the UNet's attention sites.  The reference's unmodified register_attention_control
+    (models/p2p/attention_control.py:12-81) walks `model.unet.named_children()`, recognises modules by this CLASS NAME (:63) and
+    assigns each a new `.forward` closure over the controller (:64).  The assignment is what the native UNet listens for: it reads
+    the controller out of the closure and routes the whole UNet through it (kernel descriptor when the controller's edit is one the
+    library knows, the materialise-and-call-back path of pnpi_set_attention_callback otherwise)."""
+
+    def __init__(self, unet, index, place, is_cross, heads, dim_head):
+        d = self.__dict__
+        d["_unet"], d["index"], d["place_in_unet"], d["is_cross"] = unet, index, place, is_cross
+        d["heads"], d["scale"] = heads, dim_head ** -0.5
+        d["to_q"] = d["to_k"] = d["to_v"] = d["to_out"] = _NotExecuted()
+
+    def children(self):
+        return iter(())
+
+    def reshape_heads_to_batch_dim(self, t):
+        raise RuntimeError("attention-site marker: not executed in Python")
+
+    reshape_batch_dim_to_heads = reshape_heads_to_batch_dim
+
+    def __setattr__(self, name, value):
+        if name == "forward":
+            self._unet._site_hooked(self, value)
+        self.__dict__[name] = value
+
+
+class _SiteContainer:
+    """down / mid / up container of attention-site markers (what `named_children()` yields)."""
+
+    def __init__(self, sites):
+        self._sites = list(sites)
+
+    def children(self):
+        return iter(self._sites)
+
+
+def _controller_of_hook(fn):
+    """The controller a hooked `forward` closes over (attention_control.py:20-47: free variable `controller`)."""
+    code, cells = getattr(fn, "__code__", None), getattr(fn, "__closure__", None)
+    if code is not None and cells:
+        for name, cell in zip(code.co_freevars, cells):
+            if name == "controller":
+                return cell.cell_contents
+    raise TypeError("an attention site of the native UNet was given a forward hook that does not close over a `controller` "
+                    "(the reference's register_attention_control protocol): the native UNet cannot run arbitrary Python attention")
+
+
 class NativeUNet:
-    """Callable with the reference's UNet protocol.  A registered controller (see p2p.attention_control.register_attention_control)
-    is translated into the kernel descriptor; it applies to batches laid out [uncond_src, uncond_tgt, cond_src, cond_tgt]."""
+    """Callable with the reference's UNet protocol.  A registered controller (see p2p.attention_control.register_attention_control,
+    or the reference's own unmodified function through the attention-site markers of named_children()) is translated into the kernel
+    descriptor; it applies to batches laid out [uncond_src, uncond_tgt, cond_src, cond_tgt]."""
 
     def __init__(self, engine: NativeEngine):
         self.engine = engine
@@ -57,12 +114,48 @@ class NativeUNet:
         cfg = engine.cfg
         n_attn_blocks = sum(cfg.block_has_attn)
         self.num_att_layers = 2 * (cfg.layers_per_block * n_attn_blocks + 1 + (cfg.layers_per_block + 1) * n_attn_blocks)
+        # attention-site markers in the order the forward visits them: per transformer block attn1 (self), attn2 (cross)
+        heads = cfg.heads
+        sites = {"down": [], "mid": [], "up": []}
+
+        def add(place, channels, count):
+            for _ in range(count):
+                for is_cross in (False, True):
+                    sites[place].append(CrossAttention(self, sum(len(v) for v in sites.values()), place, is_cross, heads, channels // heads))
+        boc = list(cfg.block_out_channels)
+        for i, has in enumerate(cfg.block_has_attn):
+            if has:
+                add("down", boc[i], cfg.layers_per_block)
+        add("mid", boc[-1], 1)
+        for i, has in reversed(list(enumerate(cfg.block_has_attn))):
+            if has:
+                add("up", boc[i], cfg.layers_per_block + 1)
+        self._sites = sites
+        assert sum(len(v) for v in sites.values()) == self.num_att_layers
 
     def set_controller(self, controller):
+        from .p2p.attention_control import is_callback_controller
         self.controller = controller
+        if not is_callback_controller(controller) and getattr(self, "_cb_for", None) is not None:
+            # a host callback left by an earlier callback controller must not outlive it: the loop entry points (level 2) and the next
+            # descriptor forward would otherwise run the stale Python controller
+            self.engine.set_attention_callback(None)
+            self._cb_for = None
 
     def named_children(self):
-        return iter(())
+        """(name, container) pairs whose names contain "down" / "mid" / "up" (attention_control.py:72-79) and whose children are the
+        attention-site markers the reference's register_attention_control hooks."""
+        return iter([("down_blocks", _SiteContainer(self._sites["down"])), ("mid_block", _SiteContainer(self._sites["mid"])),
+                     ("up_blocks", _SiteContainer(self._sites["up"]))])
+
+    def _site_hooked(self, site, fn):
+        """An attention-site marker was assigned a `.forward` (the reference's register_attention_control, attention_control.py:64): every
+        site of one registration closes over the same controller, and each registration starts again at the first site."""
+        from .p2p.attention_control import adapt_foreign_controller
+        raw = _controller_of_hook(fn)
+        if site.index == 0 or getattr(self, "_hooked_raw", None) is not raw:
+            self._hooked_raw = raw
+            self.set_controller(adapt_foreign_controller(raw))
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
         rows = sample.shape[0]
