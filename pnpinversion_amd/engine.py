@@ -332,6 +332,19 @@ class NativeEngine:
         self._keep = (e, s)
         return out
 
+    def cfg_ddim_prev(self, eps, x, t, ratio, guidance_scale, noise_loss=None, offset_rows=0):
+        """One image's CFG combine + DDIM step (+ the direct-inversion offset on the first offset_rows rows): eps [2R, 4, h, w]
+        (R unconditional rows, then R conditional), x [R, 4, h, w] -> [R, 4, h, w]   (p2p_guidance_forward.py:108-114)"""
+        e, xs = self._f32(eps), self._f32(x)
+        R = xs.shape[0]
+        assert e.shape[0] == 2 * R
+        nl = self._f32(noise_loss) if noise_loss is not None else None
+        out = torch.empty_like(xs)
+        self._call("pnpi_cfg_ddim_prev", _p(e), _p(xs), 1, R, xs[0].numel(), float(guidance_scale), int(t), int(ratio), _p(nl),
+                   int(offset_rows) if nl is not None else 0, None, 1.0, None, _p(out), None, 0, None)
+        self._keep = (e, xs, nl)
+        return out
+
     def ddim_prev_step_recon(self, eps, t, ratio, sample, ref_image, recon_lr, recon_mask=None):
         """DDIMSchedulerDev.step with ref_image / recon_lr / recon_mask (scheduler_dev.py:68-76) -> (prev_sample, pred_original_sample)"""
         e, s = self._f32(eps), self._f32(sample)

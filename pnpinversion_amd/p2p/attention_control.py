@@ -184,15 +184,16 @@ def make_controller(pipeline, prompts, is_replace_controller, cross_replace_step
 
 
 def controller_tables(controller):
-    """Host tables (kernel descriptor) of a registered controller, None for "no edit".  An object without `.tables()` -- e.g. an
-    instance of the reference's own callback classes (models/p2p/attention_control.py:151-363) or of a user subclass of them --
-    would be called at every attention site by the reference; silently ignoring it would be a wrong edit, so it raises."""
+    """Host tables (kernel descriptor) of a registered controller, None for "no edit".  An object without `.tables()` -- e.g. a user
+    subclass of the reference's callback classes (models/p2p/attention_control.py:151-363) -- has no descriptor: it runs through the
+    level-1 call-back path (NativeUNet.__call__, and the Python step loops of p2p_guidance_forward for callback controllers), never
+    through a loop entry point of the library, so asking for its tables is an error."""
     if controller is None:
         return None
     if not hasattr(controller, "tables"):
-        raise TypeError("controller %s has no native descriptor (.tables()) and is not callable as controller(attn, is_cross, place); "
-                        "build it with pnpinversion_amd.p2p.attention_control (same class names / arguments as "
-                        "models/p2p/attention_control.py)" % type(controller).__name__)
+        raise TypeError("controller %s has no kernel descriptor (.tables()); controllers of the reference's call-back protocol "
+                        "`controller(attn, is_cross, place)` are supported through model.unet(...) and the guidance-forward functions "
+                        "(level 1), not through the device-resident loop entry points" % type(controller).__name__)
     return controller.tables()
 
 
@@ -203,10 +204,96 @@ def is_callback_controller(controller):
     return controller is not None and not hasattr(controller, "tables") and callable(controller)
 
 
+class ForeignControllerAdapter:
+    """An instance of the REFERENCE's own controller classes (models/p2p/attention_control.py, unmodified) whose edit the kernels know:
+    AttentionReplace / AttentionRefine / AttentionReweight without LocalBlend.  Their attributes are the same tensors this module's
+    classes build (mapper, alphas, equalizer, cross_replace_alpha, num_self_replace), so the descriptor is read off the object.  Step
+    bookkeeping (cur_step, between_steps, step_callback) stays on the wrapped object, where the reference's loop code reads it."""
+
+    def __init__(self, wrapped):
+        self.__dict__["wrapped"] = wrapped
+
+    def __getattr__(self, name):
+        return getattr(self.wrapped, name)
+
+    def __setattr__(self, name, value):
+        setattr(self.wrapped, name, value)
+
+    def tables(self):
+        return _tables_from_attributes(self.wrapped)
+
+
+def _mapper_alphas_from_attributes(c):
+    name = type(c).__name__
+    ones = np.ones(MAX_NUM_WORDS, dtype=np.float32)
+    if name == "AttentionReplace":
+        return c.mapper[0].detach().float().cpu().numpy(), ones
+    if name == "AttentionRefine":
+        idx = c.mapper[0].detach().cpu().numpy()
+        m = np.zeros((MAX_NUM_WORDS, MAX_NUM_WORDS), dtype=np.float32)
+        for j, w in enumerate(idx):
+            m[int(w) % MAX_NUM_WORDS, j] = 1.0
+        return m, c.alphas.detach().float().cpu().reshape(-1).numpy()
+    if name == "AttentionReweight":
+        prev = getattr(c, "prev_controller", None)
+        return _mapper_alphas_from_attributes(prev) if prev is not None else (np.eye(MAX_NUM_WORDS, dtype=np.float32), ones)
+    raise LookupError(name)
+
+
+def _tables_from_attributes(c):
+    cra = c.cross_replace_alpha.detach().float().cpu()
+    steps = cra.shape[0] - 1
+    mapper, alphas = _mapper_alphas_from_attributes(c)
+    eq = (c.equalizer.detach().float().cpu().reshape(-1).numpy() if type(c).__name__ == "AttentionReweight"
+          else np.ones(MAX_NUM_WORDS, dtype=np.float32))
+    return ControllerTables(cross_alpha=cra.reshape(steps + 1, MAX_NUM_WORDS).numpy(), mapper=mapper, alphas=alphas, equalizer=eq,
+                            self_range=tuple(int(x) for x in c.num_self_replace), lb_alpha=None, lb_start=0, lb_threshold=0.3)
+
+
+def adapt_foreign_controller(controller):
+    """What NativeUNet does with the controller the reference's unmodified register_attention_control closed over:
+      * its DummyController (controller=None, attention_control.py:49-56), EmptyControl and a plain AttentionStore: no edit -> None
+        (AttentionStore's stored maps are then NOT populated: only visualisation reads them; keep them by passing the object through
+        `force_callback(controller)`);
+      * this module's own classes: unchanged (they carry `.tables()`);
+      * the reference's AttentionReplace / Refine / Reweight WITHOUT LocalBlend: the kernel descriptor read off their attributes;
+      * anything else callable (LocalBlend needs the stored 16 x 16 maps; user subclasses): the call-back path, exact and slow."""
+    if controller is None or hasattr(controller, "tables"):
+        return controller
+    if getattr(controller, "_pnpi_force_callback", False):
+        return controller
+    name = type(controller).__name__
+    if name in ("DummyController", "EmptyControl"):
+        return None
+    if name == "AttentionStore":
+        return _NoEditAdapter(controller)
+    if name in ("AttentionReplace", "AttentionRefine", "AttentionReweight") and getattr(controller, "local_blend", None) is None:
+        try:
+            _tables_from_attributes(controller)
+        except (LookupError, AttributeError, IndexError):
+            return controller
+        return ForeignControllerAdapter(controller)
+    return controller
+
+
+class _NoEditAdapter(ForeignControllerAdapter):
+    """A foreign AttentionStore: a plain forward, with the step bookkeeping kept on the wrapped object."""
+
+    def tables(self):
+        return None
+
+
+def force_callback(controller):
+    """Mark a controller so that it always runs through the call-back path (e.g. an AttentionStore whose stored maps are wanted)."""
+    controller._pnpi_force_callback = True
+    return controller
+
+
 def register_attention_control(model, controller):
     """The reference patches 32 CrossAttention.forward methods here (attention_control.py:12-81).  The native UNet has no
     Python attention modules; registration just hands the controller to the pipeline's UNet, which turns it into the kernel
-    descriptor at the next call."""
-    model.unet.set_controller(controller)
+    descriptor at the next call.  (The reference's OWN unmodified function works too: NativeUNet.named_children() yields markers of
+    class CrossAttention whose `.forward` assignment does the same.)"""
+    model.unet.set_controller(adapt_foreign_controller(controller))
     if controller is not None and hasattr(controller, "num_att_layers"):
         controller.num_att_layers = model.unet.num_att_layers

@@ -4,7 +4,7 @@ LocalBlend) runs as one device-resident pnpi_edit_loop call."""
 import torch
 
 from ..utils.utils import init_latent
-from .attention_control import controller_tables, register_attention_control
+from .attention_control import controller_tables, is_callback_controller, register_attention_control
 
 
 def _encode_prompts(model, prompt):
@@ -17,6 +17,20 @@ def _encode_prompts(model, prompt):
     return torch.cat([uncond_embeddings, text_embeddings])            # [unc_src, unc_tgt, cond_src, cond_tgt]
 
 
+def _level1_loop(model, controller, latents, context_of_step, guidance_scale, noise_loss_list, offset_rows):
+    """The reference's Python step loop (p2p_guidance_forward.py:21-62,103-116,135-173) for a controller of the call-back protocol
+    (no kernel descriptor): per step one 4-row model.unet(...) call -- NativeUNet materialises the probabilities of the 32 attention
+    sites and calls `controller(attn, is_cross, place)` at each -- then the fused CFG / DDIM-step / offset kernel and the controller's
+    own step_callback.  Slow and exact; the device-resident loops are for controllers with a descriptor."""
+    ratio = model.scheduler.step_ratio
+    for i, t in enumerate(model.scheduler.timesteps):
+        eps = model.unet(torch.cat([latents] * 2), t, encoder_hidden_states=context_of_step(i))["sample"]
+        nl = noise_loss_list[i] if noise_loss_list is not None else None
+        latents = model.engine.cfg_ddim_prev(eps, latents, int(t), ratio, guidance_scale, noise_loss=nl, offset_rows=offset_rows)
+        latents = controller.step_callback(latents)
+    return latents
+
+
 def _run(model, prompt, controller, latent, num_inference_steps, guidance_scale, generator, noise_loss_list, add_offset,
          offset_rows):
     batch_size = len(prompt)
@@ -27,7 +41,11 @@ def _run(model, prompt, controller, latent, num_inference_steps, guidance_scale,
     context = _encode_prompts(model, prompt)
     latent, latents = init_latent(latent, model, height, width, generator, batch_size)
     model.scheduler.set_timesteps(num_inference_steps)
-    tables = controller_tables(controller)
+    ctrl = model.unet.controller          # the registered form (a foreign controller object may have been adapted)
+    if is_callback_controller(ctrl):
+        out = _level1_loop(model, ctrl, latents, lambda i: context, guidance_scale, noise_loss_list if add_offset else None, offset_rows)
+        return out, latent
+    tables = controller_tables(ctrl)
     nl = None
     if noise_loss_list is not None and add_offset:
         nl = torch.stack(list(noise_loss_list))[:, None]               # [steps, 1, 2, 4, h, w]
@@ -88,7 +106,18 @@ def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 5
     if batch_size == 1:   # the kernel batch is [unc_a, unc_b, cond_a, cond_b]: run the single prompt as both rows of a pair
         uncond, text = uncond.expand(2, *uncond.shape[1:]), text.expand(2, *text.shape[1:])
     context = torch.cat([uncond, text])
-    tables = controller_tables(controller)
+    ctrl = model.unet.controller          # the registered form (a foreign controller object may have been adapted)
+    if is_callback_controller(ctrl):
+        if prox is not None or recon is not None or batch_size != 2:
+            raise NotImplementedError("call-back controllers run the plain two-prompt guidance loop only (no proximal step, no reconstruction guidance)")
+        def context_of_step(i):
+            if per_step is None:
+                return context
+            c = context.clone()
+            c[:1 if single_branch else 2] = per_step[i].to(context.device)
+            return c
+        return _level1_loop(model, ctrl, latents, context_of_step, guidance_scale, None, 0), latent
+    tables = controller_tables(ctrl)
     if prox is not None and batch_size != 2:
         raise NotImplementedError("the proximal step takes its quantile over the (source, target) pair")
     if per_step is not None:      # null-text inversion: the step's embedding on every unconditional row (:56-57) or the first only (:92)

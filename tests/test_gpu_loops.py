@@ -508,3 +508,115 @@ def test_masactrl_driver_cli(tmp_path, capsys):
     assert capsys.readouterr().out.count("editing image") == 4
     drv.main(argv)
     assert capsys.readouterr().out.count("skip image") == 4
+
+
+def test_level1_boundary_callback_state_scheduler_pull_and_callback_loop(small64):
+    """SURVEY 8b level 1, the pieces around the call-back path:
+    (1) a host attention callback still installed makes every loop entry point fail loudly (it would silently replace the descriptor
+        edits); NativeUNet.set_controller drops a stale one;
+    (2) DDIMSchedulerDev.step(ref_image=, recon_lr=, recon_mask=) (scheduler_dev.py:68-76), bit for bit against the formula;
+    (3) a controller of the reference's call-back protocol, registered through a function shaped like the reference's own
+        register_attention_control (closure over `controller`, markers of class CrossAttention), drives
+        direct_inversion_p2p_guidance_forward step by step and lands where the kernel-descriptor controller of the same edit does."""
+    from pnpinversion_amd._capi import PnpiError
+    from pnpinversion_amd.p2p.p2p_guidance_forward import direct_inversion_p2p_guidance_forward
+    pipe = small64
+    eng = pipe.engine
+    cfg = eng.cfg
+    steps = 3
+    pipe.scheduler.set_timesteps(steps)
+    ts = pipe.scheduler.timesteps.numpy()
+    g = torch.Generator().manual_seed(77)
+    z0 = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=g) * 0.5
+    ctx = weights.synth_context(cfg, 4, seed=78)
+
+    # (1)
+    eng.set_attention_callback(lambda attn, is_cross, place, layer: None, rows=4)
+    with pytest.raises(PnpiError, match="attention callback is installed"):
+        eng.ddim_invert(z0, ctx[2:3], ts)
+    eng.set_attention_callback(None)
+    xs = eng.ddim_invert(z0, ctx[2:3], ts)
+    pipe.unet._cb_for = object()           # as if a call-back controller had run
+    eng.set_attention_callback(lambda attn, is_cross, place, layer: None, rows=4)
+    pipe.unet.set_controller(None)
+    assert torch.equal(eng.ddim_invert(z0, ctx[2:3], ts), xs)
+
+    # (2)
+    eps = torch.randn(2, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    x = torch.randn(2, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    ref_img = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    mask = (torch.rand(2, 1, cfg.sample_size, cfg.sample_size, generator=g) > 0.5)
+    t = int(ts[1])
+    ac_ = pipe.scheduler.alphas_cumprod
+    a_t, a_p = ac_[t], ac_[t - pipe.scheduler.step_ratio]
+    for m in (mask, None):
+        out = pipe.scheduler.step(eps.cuda(), t, x.cuda(), ref_image=ref_img.cuda(), recon_lr=0.1, recon_mask=None if m is None else m.cuda())
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        pull = 0.1 * (x0 - ref_img.expand_as(x0))
+        x0 = x0 - (pull * m.expand_as(x0).float() if m is not None else pull)
+        want = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+        assert torch.equal(out["prev_sample"].cpu(), want) and torch.equal(out["pred_original_sample"].cpu(), x0)
+    plain = pipe.scheduler.step(eps.cuda(), t, x.cuda(), ref_image=ref_img.cuda(), recon_lr=0.0)["prev_sample"]
+    assert torch.equal(plain, pipe.scheduler.step(eps.cuda(), t, x.cuda())["prev_sample"])
+
+    # (3)
+    prompts = ["a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate"]
+    native = ac.make_controller(pipe, prompts, True, {"default_": 0.4}, 0.6, None, {"words": ("square",), "values": (2,)}, num_ddim_steps=steps)
+    tb = {"kind": "replace", "mapper": native.prev_controller.mapper[0].cuda(), "equalizer": native.equalizer.reshape(-1).cuda(),
+          "cross_alpha": native.cross_replace_alpha.reshape(steps + 1, 77).cuda(), "self_range": native.num_self_replace, "lb": None}
+
+    class RefProtocolController:           # models/p2p/attention_control.py:151-190: called at every attention site; counts its own steps
+        def __init__(self):
+            self.inner = po.EditController(pipe.unet.num_att_layers, tb)
+            self.num_att_layers = -1
+            self.calls = 0
+
+        def __call__(self, attn, is_cross, place_in_unet):
+            self.calls += 1
+            return self.inner(attn, is_cross, place_in_unet)
+
+        def step_callback(self, x_t):
+            return x_t
+
+    def reference_shaped_register(model, controller):      # attention_control.py:12-81, condensed
+        def ca_forward(self, place_in_unet):
+            def forward(x, context=None, mask=None, **kwargs):
+                raise AssertionError("never executed: the attention runs in libpnpi")
+                return controller(x, context is not None, place_in_unet)
+            return forward
+
+        def rec(net_, count, place):
+            if net_.__class__.__name__ == "CrossAttention":
+                net_.forward = ca_forward(net_, place)
+                return count + 1
+            for ch in net_.children():
+                count = rec(ch, count, place)
+            return count
+        n = 0
+        for name, net in model.unet.named_children():
+            n += rec(net, 0, "down" if "down" in name else ("up" if "up" in name else "mid"))
+        controller.num_att_layers = n
+
+    cb = RefProtocolController()
+    reference_shaped_register(pipe, cb)
+    assert cb.num_att_layers == 32 and pipe.unet.controller is cb
+    from pnpinversion_amd.p2p.p2p_guidance_forward import _encode_prompts
+    context = _encode_prompts(pipe, prompts)                 # what both loops will embed themselves
+    xs = eng.ddim_invert(z0, context[2:3], ts)
+    nl = eng.offset_calculate(xs, context[None], ts, 7.5)
+    nl_list = [nl[i, 0] for i in range(steps)]
+    out_cb, _ = direct_inversion_p2p_guidance_forward(pipe, prompts, cb, latent=xs[-1], num_inference_steps=steps, guidance_scale=7.5,
+                                                      noise_loss_list=nl_list)
+    assert cb.calls == 32 * steps
+    out_native, _ = direct_inversion_p2p_guidance_forward(pipe, prompts, native, latent=xs[-1], num_inference_steps=steps,
+                                                          guidance_scale=7.5, noise_loss_list=nl_list)
+    # two arithmetic paths for the probabilities (materialised fp32 -> fp16 vs the flash kernel's), classifier-free guidance multiplies
+    # the difference by 7.5 at each of the 3 steps; the edit itself (target vs source row) is an order of magnitude larger
+    r = rel(out_cb, out_native)
+    edit = rel(out_native[1], out_native[0])
+    print("call-back loop vs descriptor loop: rel %.4f; size of the edit %.3f" % (r, edit))
+    assert r < 5e-2 and edit > 5 * r, (r, edit)
+    # (the offsets cancel only against the forward they were computed with -- DESIGN section 3, faithfulness note 2 -- so it is the
+    # descriptor loop, whose arithmetic produced them, whose source branch returns to z0)
+    assert rel(out_native[0], xs[0, 0]) < 1.5e-2
+    pipe.unet.set_controller(None)

@@ -171,7 +171,7 @@ def test_attention_callback_fallback_for_controllers_without_descriptor(tiny):
         unet(lat, 500, encoder_hidden_states=ctx)
     ac.register_attention_control(SimpleNamespace(unet=unet), None)
     assert torch.equal(unet(lat, 500, encoder_hidden_states=ctx)["sample"], fused)
-    with pytest.raises(TypeError, match="no native descriptor"):
+    with pytest.raises(TypeError, match="no kernel descriptor"):
         ac.register_attention_control(SimpleNamespace(unet=unet), object())
         unet(lat, 500, encoder_hidden_states=ctx)
     ac.register_attention_control(SimpleNamespace(unet=unet), None)

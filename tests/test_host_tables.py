@@ -198,3 +198,131 @@ def test_random_prompt_pairs_against_the_live_reference():
         lb = ac.LocalBlend([ps, pt], ((w0,), (w1,)), tokenizer=tok, num_ddim_steps=50)
         assert torch.equal(torch.as_tensor(lb.alpha_layers).reshape(-1), rlb.alpha_layers.reshape(-1).cpu()) and lb.start_blend == rlb.start_blend
     assert n_replace >= 5
+
+
+class _FakeEngine:
+    """What NativeUNet needs from an engine to build its attention-site markers (no GPU): the model configuration."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.callback = "unset"
+
+    def set_attention_callback(self, fn):
+        self.callback = fn
+
+
+def test_the_references_own_register_attention_control_hooks_the_native_unet():
+    """SURVEY 8b level 1 with the reference's UNMODIFIED code (build container only): models/p2p/attention_control.register_attention_control
+    walks NativeUNet.named_children(), finds the 32 markers of class `CrossAttention` (:62-81), assigns their .forward -- and the native UNet
+    ends up with the controller the closure carries: a kernel descriptor for the reference's own AttentionReplace / Refine / Reweight objects
+    (read off their attributes, bit-identical to this package's classes), the call-back path for LocalBlend, nothing for controller=None."""
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree not on this machine")
+    ref_shim.install()
+    import types
+    import torch
+    from models.p2p import attention_control as ref_ac
+    from pnpinversion_amd.config import SD1
+    from pnpinversion_amd.pipeline import NativeUNet
+    tok = WordTokenizer()
+    eng = _FakeEngine(SD1)
+    model = types.SimpleNamespace(unet=NativeUNet(eng), tokenizer=tok, device="cpu")
+    names = [n for n, _ in model.unet.named_children()]
+    assert any("down" in n for n in names) and any("mid" in n for n in names) and any("up" in n for n in names)
+
+    # controller=None: the reference's DummyController is counted up to 32 and means "no controller"
+    ref_ac.register_attention_control(model, None)
+    assert model.unet.controller is None
+
+    ps, pt = "a cat sitting on a wooden chair", "a dog sitting on a wooden chair"
+    prompts = [ps, pt]
+    with ref_shim.cuda_to_cpu():
+        ref_replace = ref_ac.AttentionReplace(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok)
+        ref_refine = ref_ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok)
+        eq = ref_ac.get_equalizer(pt, ("dog",), (2,), tokenizer=tok)
+        ref_rw = ref_ac.AttentionReweight(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, equalizer=eq,
+                                          controller=ref_refine)          # (the reference's Reweight takes no tokenizer, :347-355)
+        ref_lb = ref_ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok,
+                                        local_blend=ref_ac.LocalBlend(prompts, (("cat",), ("dog",)), tokenizer=tok, num_ddim_steps=50))
+        ref_store = ref_ac.AttentionStore()
+    mine_replace = ac.AttentionReplace(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok)
+    mine_refine = ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok)
+    mine_rw = ac.AttentionReweight(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6,
+                                   equalizer=ac.get_equalizer(pt, ("dog",), (2,), tokenizer=tok), controller=mine_refine, tokenizer=tok)
+
+    def same_tables(a, b):
+        for k in ("cross_alpha", "mapper", "alphas", "equalizer"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        assert a.self_range == b.self_range and a.lb_alpha is None and b.lb_alpha is None
+
+    for ref_c, mine in ((ref_replace, mine_replace), (ref_refine, mine_refine), (ref_rw, mine_rw)):
+        ref_ac.register_attention_control(model, ref_c)
+        assert ref_c.num_att_layers == 32                                   # the reference counted 32 sites
+        got = model.unet.controller
+        assert isinstance(got, ac.ForeignControllerAdapter) and got.wrapped is ref_c and not ac.is_callback_controller(got)
+        same_tables(got.tables(), mine.tables())
+        got.cur_step += 1                                                   # step bookkeeping lands on the reference's object
+        assert ref_c.cur_step == 1
+        ref_c.cur_step = 0
+
+    # LocalBlend reads the stored 16 x 16 maps: the reference's object runs through the call-back path, untouched
+    ref_ac.register_attention_control(model, ref_lb)
+    assert model.unet.controller is ref_lb and ac.is_callback_controller(model.unet.controller) and ref_lb.num_att_layers == 32
+    # a plain AttentionStore: no edit (its step bookkeeping still runs on the reference's object)
+    ref_ac.register_attention_control(model, ref_store)
+    assert model.unet.controller.tables() is None and model.unet.controller.wrapped is ref_store
+    # this package's own classes through the reference's function: unchanged
+    ref_ac.register_attention_control(model, mine_rw)
+    assert model.unet.controller is mine_rw and mine_rw.num_att_layers == 32
+    # a hook that is not the reference's protocol is refused, not ignored
+    site = next(iter(next(iter(model.unet.named_children()))[1].children()))
+    with pytest.raises(TypeError, match="close over a `controller`"):
+        site.forward = lambda x, context=None, mask=None: x
+
+
+def test_native_unet_attention_site_markers_without_the_reference():
+    """The same protocol with a locally written registration function of the reference's shape (runs everywhere)."""
+    import types
+    from pnpinversion_amd.config import SD1, SMALL64_LB
+    from pnpinversion_amd.pipeline import NativeUNet
+
+    def register(model, controller):           # models/p2p/attention_control.py:12-81, condensed
+        def ca_forward(self, place_in_unet):
+            def forward(x, context=None, mask=None, **kwargs):
+                return controller(x, context is not None, place_in_unet)
+            return forward
+
+        def rec(net_, count, place):
+            if net_.__class__.__name__ == "CrossAttention":
+                net_.forward = ca_forward(net_, place)
+                return count + 1
+            for ch in net_.children():
+                count = rec(ch, count, place)
+            return count
+        n = 0
+        for name, net in model.unet.named_children():
+            for place in ("down", "up", "mid"):
+                if place in name:
+                    n += rec(net, 0, place)
+        controller.num_att_layers = n
+
+    class Probe:
+        def __call__(self, attn, is_cross, place):
+            return attn
+
+    for cfg, want in ((SD1, 32), (SMALL64_LB, 22)):
+        eng = _FakeEngine(cfg)
+        unet = NativeUNet(eng)
+        model = types.SimpleNamespace(unet=unet)
+        p = Probe()
+        register(model, p)
+        assert p.num_att_layers == want == unet.num_att_layers and unet.controller is p and ac.is_callback_controller(p)
+        sites = [s for _, cont in unet.named_children() for s in cont.children()]
+        assert [s.is_cross for s in sites] == [False, True] * (want // 2) and [s.index for s in sites] == list(range(want))
+        first = cfg.block_out_channels[[i for i, h in enumerate(cfg.block_has_attn) if h][0]]
+        assert sites[0].heads == cfg.heads and abs(sites[0].scale - (first // cfg.heads) ** -0.5) < 1e-12
+        # replacing it with a descriptor controller drops a callback the engine still holds
+        unet._cb_for = p
+        unet.set_controller(None)
+        assert eng.callback is None and unet._cb_for is None
