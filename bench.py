@@ -144,10 +144,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    from pnpinversion_amd.distributed import prepare_env
+    prepare_env()                      # dmabuf IPC + 127.0.0.1 rendezvous, before RCCL initialises (also when the driver launches the ranks)
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from pnpinversion_amd.config import SD1
@@ -161,8 +162,9 @@ def main():
                           text_encoder="native")        # prompts are embedded by the device CLIP text transformer (A1)
     if rank == 0:
         pipe.load_state_dict(weights.unet_state_dict(cfg, 0), weights.vae_state_dict(cfg, 0), clip_sd=weights.clip_state_dict(cfg, 0))
+    bcast = {}
     if world > 1:
-        broadcast_weights(pipe.engine, src=0)       # the one collective: RCCL broadcast of the packed arena over xGMI
+        broadcast_weights(pipe.engine, src=0, stats=bcast)       # the one collective: RCCL broadcast of the packed arena over xGMI
     editor = P2PEditor(["directinversion+p2p"], "cuda:%d" % local_rank, num_ddim_steps=args.ddim_steps, pipeline=pipe)
     editor.lockstep = args.schedule == "lockstep"
     eng = pipe.engine
@@ -268,6 +270,29 @@ def main():
                   "executed_tflop_per_image": executed_flops(cp) / 1e12, "executed_tflops_per_gpu": executed_flops(cp) / dtp / 1e12,
                   "note": "same edit, source latent assigned from the inversion trajectory (3-row launches); parity-tested against the faithful schedule"}
 
+    # extra (never `value`): BASELINE config 4 -- "null-text-inversion+p2p" on the same image: DDIM inversion, the per-step optimisation of
+    # the unconditional embedding (up to 10 Adam iterations, each a recording UNet forward + the reverse walk to the 77 x 768 embedding),
+    # then the two guidance passes with the per-step embeddings.  FLOPs are the library's executed counters (backward launches included).
+    null_text = None
+    if world == 1 and not args.no_extras:
+        try:
+            ed_nt = P2PEditor(["null-text-inversion+p2p"], "cuda:%d" % local_rank, num_ddim_steps=args.ddim_steps, pipeline=pipe)
+            barrier()
+            eng.reset_counters()
+            tn = time.perf_counter()
+            ed_nt("null-text-inversion+p2p", image_path=images[999], prompt_src=PROMPT_SRC, prompt_tar=PROMPT_TGT, guidance_scale=7.5,
+                  cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=(("cat",), ("dog",)), eq_params={"words": ("dog",), "values": (2,)})
+            barrier()
+            dtn = time.perf_counter() - tn
+            cn = eng.counters()
+            ex = cn["executed_gemm_flops"] + cn["executed_attn_flops"]
+            null_text = {"value": 1.0 / dtn, "unit": "images/s", "s_per_image": dtn, "unet_sample_forwards": cn["unet_sample_forwards"],
+                         "unet_backward_rows": cn["unet_backward_rows"], "executed_tflop_per_image": ex / 1e12, "executed_tflops_per_gpu": ex / dtn / 1e12,
+                         "note": "null-text-inversion+p2p, %d DDIM steps x 10 Adam iterations (synthetic weights never reach the early-stop "
+                                 "threshold); executed FLOPs = 2*M*N*K of every GEMM / attention launch incl. the backward pass" % args.ddim_steps}
+        except Exception as e:   # an extra must never take the headline line down
+            null_text = {"error": "%s: %s" % (type(e).__name__, e)}
+
     batched = None
     if args.batch_images > 1 and args.schedule == "lockstep" and not args.no_extras:
         nb = args.batch_images
@@ -323,7 +348,9 @@ def main():
     if rank == 0:
         # HBM-side traffic of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of
         # this same command, reduced by tools/pmc_summary.py (gfx950 correction applied there) and committed under profiles/.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_traffic.json")
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        pmc = next((os.path.join(prof, f) for f in ("round3_pmc_traffic_bench.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json")
+                    if os.path.exists(os.path.join(prof, f))), os.path.join(prof, "round2_pmc_traffic.json"))
         if roofline is not None and os.path.exists(pmc):
             tag = roofline["kernel"].replace(" ", "")           # igemm_dma_kernel<128,128,64,2,2,0,1>
             for name, v in json.load(open(pmc))["kernels"].items():
@@ -335,8 +362,9 @@ def main():
                     roofline["traffic_over_alg"] = v.get("traffic_over_alg")
                     if "mfma_util" in v:
                         roofline["mfma_busy"] = v["mfma_util"]
-                    roofline["traffic_source"] = ("profiles/round2_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of 12-row "
-                                                  "UNet forwards (tools/fwd_only.py), mean per launch of this kernel")
+                    src_json = json.load(open(pmc))
+                    roofline["traffic_source"] = "profiles/%s: %s" % (os.path.basename(pmc), src_json.get(
+                        "source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of 12-row UNet forwards (tools/fwd_only.py), mean per launch of this kernel"))
                     break
         n_img = args.steps * world
         per_rank_flops = executed_flops(ctr)
@@ -351,6 +379,8 @@ def main():
                        "ddim_steps": args.ddim_steps, "images_per_step_per_gpu": 1, "schedule": args.schedule,
                        "unet_sample_forwards_per_image": ctr["unet_sample_forwards"] / max(1, args.steps),
                        "algorithmic_tflop_per_image": per_rank_flops / max(1, args.steps) / 1e12},
+            "rccl_ranks": world if world > 1 else 0,
+            "bcast_ms": bcast.get("ms"), "bcast_mb": (bcast.get("bytes", 0) / 1e6) if bcast else None,   # the start-up weight broadcast (untimed set-up)
             "whole_path_tflops_per_gpu": per_rank_flops / dt / 1e12,
             "whole_path_mfma_frac": per_rank_flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
             "roofline": roofline,
@@ -361,6 +391,8 @@ def main():
             out["batched"] = batched
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if null_text is not None:
+            out["null_text"] = null_text
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, see cpu_baseline)
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

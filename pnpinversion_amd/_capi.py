@@ -154,6 +154,12 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # PNPI_TUNE="key=value,key=value": process-wide kernel tuning knobs (pnpi_set_tuning) applied at load -- whole test files / the bench
+    # under a non-default kernel variant without touching their code
+    for kv in filter(None, os.environ.get("PNPI_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        if lib.pnpi_set_tuning(k.strip().encode(), int(v)) != 0:
+            raise ValueError("PNPI_TUNE: unknown tuning key %r" % k)
     if path is None:
         _lib = lib
     return lib

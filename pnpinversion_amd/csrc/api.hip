@@ -651,6 +651,7 @@ static int transformer_fwd_tape(pnpi_ctx* c, const TransformerW& t, const half_t
     AttnP a; a.q = qkv; a.ldq = 3 * hd; a.q_off = 0; a.k = qkv; a.ldk = 3 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv;
     a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale; a.rows = c->cd.rows_id; a.nrows = B;
     CK(launch_attn_flash(a, c->st));
+    c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
     if (taping(c)) {
       TapeOp o; o.kind = TK_ATTN; o.q = qkv; o.ldq = 3 * hd; o.q_off = 0; o.k = qkv; o.ldk = 3 * hd; o.k_off = hd; o.v = qkv; o.ldv = 3 * hd; o.v_off = 2 * hd;
       o.out = ao; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = N; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B;
@@ -674,6 +675,7 @@ static int transformer_fwd_tape(pnpi_ctx* c, const TransformerW& t, const half_t
     AttnP a; a.q = q2; a.ldq = hd; a.q_off = 0; a.k = kv2; a.ldk = 2 * hd; a.k_off = 0; a.vt = vt2; a.ldv = ldv2;
     a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale; a.rows = c->cd.rows_id; a.nrows = B;
     CK(launch_attn_flash(a, c->st));
+    c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * 96 * t.Dp;
     if (taping(c)) {
       TapeOp o; o.kind = TK_ATTN; o.q = q2; o.ldq = hd; o.q_off = 0; o.k = kv2; o.ldk = 2 * hd; o.k_off = 0; o.v = kv2; o.ldv = 2 * hd; o.v_off = hd;
       o.out = ao2; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = T; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B;
@@ -1207,6 +1209,10 @@ static int text_kv_precompute(pnpi_ctx* c, const float* context, int rows) {
     half_t* k2 = (half_t*)(kv.base + off); off += align_up((size_t)rows * T * hd * sizeof(half_t), 256);
     half_t* vt2 = (half_t*)(kv.base + off); off += align_up((size_t)rows * hd * ldv * sizeof(half_t), 256);
     kv.k.push_back(k2); kv.vt.push_back(vt2);
+    // the V^T rows are padded to 8 keys and the blocks sit at row-count-dependent offsets: a pad column of this layout may hold another
+    // row count's projection data (or anything), and the call-back path multiplies pad columns by zero probabilities -- 0 * inf = NaN.
+    // Clear the block before the projection writes the real columns (as the in-forward talloc path does).
+    if (ldv != T && hipMemsetAsync(vt2, 0, (size_t)rows * hd * ldv * sizeof(half_t), c->st) != hipSuccess) { rc = PNPI_EHIP; return; }
     VtOut v; v.outT = vt2; v.col0 = hd; v.ld = ldv; v.f32 = 0; v.rpb = T;
     rc = op_gemm(c, ctx16, X, rows * T, X, t.w_kv2, X, 2 * hd, nullptr, nullptr, 0, k2, hd, 1.f, &v, 2.0 * rows * T * 2.0 * t.C * X);
   });
@@ -1424,7 +1430,7 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
     c->bias_valid.assign(g.n_train_timesteps, 0);
     c->tkv.cap = text_kv_bytes(c, max_unet_rows);
     CKH(hipMalloc((void**)&c->tkv.base, c->tkv.cap));
-    CKH(hipMemset(c->tkv.base, 0, c->tkv.cap));   // the V^T rows are padded to 8 keys: the pad columns stay zero (call-back path multiplies them by zero probabilities)
+    CKH(hipMemset(c->tkv.base, 0, c->tkv.cap));   // (text_kv_precompute clears each V^T block again: the layout depends on the row count)
   }
   // sinusoidal timestep table, get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0), fp64 -> fp32
   // (my_diffusers/models/embeddings.py:21-60)

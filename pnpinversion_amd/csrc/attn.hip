@@ -561,11 +561,9 @@ static size_t ce_lds_bytes() {
 
 template <int DP>
 static int launch_ce(const CrossEditP& p, hipStream_t st) {
-  static unsigned long long attr_devs = 0;
+  static DeviceOnce attr_once;
   const size_t lds = ce_lds_bytes<DP>();
-  if (first_on_device(attr_devs)) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_cross_edit_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  if (int r = once_per_device(attr_once, [&]() { return (int)hipFuncSetAttribute((const void*)attn_cross_edit_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); })) return r;
   dim3 grid((p.Nq + 127) / 128, p.heads, p.npairs);
   attn_cross_edit_kernel<DP><<<grid, 256, lds, st>>>(p);
   return (int)hipGetLastError();

@@ -1,6 +1,8 @@
 // Shared device/host definitions for the pnpi gfx950 kernels.
 // CDNA4 only: 64-lane wavefronts, v_mfma_f32_32x32x16_f16, 160 KiB LDS per CU.
 #pragma once
+#include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -61,14 +63,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// hipFuncSetAttribute (dynamic-LDS opt-in) is per DEVICE: a process that drives a second device must set it there too.
-// `mask` is a function-local static; returns true the first time the calling thread's current device is seen.
-static inline bool first_on_device(unsigned long long& mask) {
+// hipFuncSetAttribute (dynamic-LDS opt-in) is per DEVICE: a process that drives a second device must set it there too, and two
+// contexts may launch the same template instance from two threads (stage-overlapped sweeps: ctypes releases the GIL).  `fn` runs once
+// per device under a mutex; the device's bit is published only after it succeeded, so no thread can launch before the attribute is set.
+struct DeviceOnce {
+  std::mutex mu;
+  std::atomic<unsigned long long> done{0};
+};
+template <class F>
+static inline int once_per_device(DeviceOnce& o, F&& fn) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-  if (mask >> dev & 1ull) return false;
-  mask |= 1ull << dev;
-  return true;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return fn();
+  if (o.done.load(std::memory_order_acquire) >> dev & 1ull) return 0;
+  std::lock_guard<std::mutex> g(o.mu);
+  if (o.done.load(std::memory_order_relaxed) >> dev & 1ull) return 0;
+  const int r = fn();
+  if (r == 0) o.done.fetch_or(1ull << dev, std::memory_order_release);
+  return r;
 }
 
 #define HIP_CHECK_RET(expr)                         \

@@ -14,45 +14,10 @@
 #include <string.h>
 
 #include "ops.h"
+#include "igemm_dma.inc"
 
 static constexpr int BK = 64;
 static constexpr int LDS_LD = BK + 8;  // halfs
-
-__device__ __forceinline__ void epilogue_store4(const GemmP& p, int m, int nb, const float* v, const float* bias) {
-  if (m >= p.M) return;
-  float o[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int n = nb + j;
-    float x = v[j] * p.alpha;
-    if (n < p.N) {
-      if (bias) x += bias[n];
-      if (p.res) x += (float)p.res[(size_t)m * p.ldres + n];
-    }
-    o[j] = x;
-  }
-  if (nb + 3 < p.vt_col0 && nb + 3 < p.N && (p.ldo & 3) == 0) {
-    half4 h;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = (half_t)o[j];
-    *reinterpret_cast<half4*>(p.out + (size_t)m * p.ldo + nb) = h;
-    return;
-  }
-  int b = 0, tok = m;
-  if (nb + 3 >= p.vt_col0) { b = m / p.rows_per_batch; tok = m - b * p.rows_per_batch; }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int n = nb + j;
-    if (n >= p.N) continue;
-    if (n < p.vt_col0) {
-      p.out[(size_t)m * p.ldo + n] = (half_t)o[j];
-    } else {
-      size_t idx = ((size_t)b * (p.N - p.vt_col0) + (n - p.vt_col0)) * p.vt_ld + tok;
-      if (p.vt_f32) ((float*)p.outT)[idx] = o[j];
-      else ((half_t*)p.outT)[idx] = (half_t)o[j];
-    }
-  }
-}
 
 template <int BM, int BN, bool FASTK>
 __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
@@ -313,512 +278,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
 //     drained by the vmcnt(0) the compiler puts in front of the one barrier per chunk.
 // Requires (C1 + C2) % 64 == 0 and C1 % 64 == 0 (every SD-1.x layer but the 4/3-channel stems, which stay on v1).
 // ------------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 static int g_tile_order = -1;   // PNPI_TILE_ORDER: force 0 / 1 (ablation)
 
-// ABL: 0 = product kernel; 1 = DMA only (no fragment reads / MFMA); 2 = compute only (no DMA); 3 = activation operand loaded for
-// the first filter tap only -- bottleneck ablations for tools/ (1-3 produce garbage).
-//
-// Tile geometry: WGM x 2 wavefronts (NT = 128 * WGM threads); a wave owns (BM / WGM) x (BN / 2) of the block tile as 32x32 MFMA
-// tiles.  Instantiated shapes (BM x BN, wave tile): 64x64 (32x32), 128x128 (64x64), 128x256 (64x128), 128x320 (64x160: 20
-// MFMAs per 32-deep k-chunk and barrier, 91 FLOP per operand byte -- the N = 320 / 640 / 1280 layers tile exactly), 256x128.
-//
-// WK > 1: K-parallel wave groups.  The block holds WK groups of WGM x 2 waves; group g owns its own LDS ring and walks the g-th
-// contiguous slice of the block's k-range into its own accumulators (the groups run in lock step on the one workgroup barrier per
-// chunk), then groups 1 .. WK-1 hand their fp32 accumulators to group 0 through LDS in a FIXED order and exit; group 0 runs the
-// epilogue.  A launch with at most one tile per CU (the one-row inversion forwards, the 16 x 16 / 8 x 8 levels) puts WK times the
-// MFMA-issuing waves on every CU this way -- split-K with the partial sums in LDS instead of slabs + a reduce launch.
-template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
-struct IgemmGeom {
-  static constexpr int NW = 2 * WGM, NT = 64 * NW;              // waves / threads of ONE k-group (= the epilogue's threads)
-  static constexpr int NT_ALL = NT * WK;
-  static constexpr int WM = BM / WGM, WN = BN / 2, MI = WM / 32, NI = WN / 32;
-  static constexpr int RPI = 1024 / (BKT * 2);                 // tile rows per 1-KiB DMA instruction (8 or 16)
-  static constexpr int AV = BM / RPI / NW, WV = BN / RPI / NW;  // DMA instructions per wave per chunk and operand
-  static constexpr int ROWB = BKT * 2;                          // bytes per tile row
-  static constexpr int STAGE = (BM + BN) * ROWB;                // bytes
-  static constexpr int RING = NST * STAGE;
-  // LDS epilogue: the output tile is staged as [rows][BN + 8] halfs in the idle ring, EPASS passes of EROWS rows (one row of
-  // waves per pass when the whole tile does not fit), then written as full rows; G row groups of VPR 16-byte vectors.
-  static constexpr int OLD = BN + 8, VPR = BN / 8, G = NT / VPR;
-  static constexpr int STATS_B = G * BN * 2 * 4;
-  static constexpr int EPASS = (BM * OLD * 2 + STATS_B <= RING) ? 1 : WGM;
-  static constexpr int EROWS = BM / EPASS;
-  static constexpr int TOLD = EROWS + 8;                        // halfs per staged row of a TRANSPOSED tile ([BN][EROWS + 8])
-  static constexpr int EPI_PLAIN = EROWS * OLD * 2 + STATS_B, EPI_TR = BN * TOLD * 2;
-  static constexpr int EPI = EPI_PLAIN > EPI_TR ? EPI_PLAIN : EPI_TR;
-  static constexpr int RED = (WK - 1) * BM * BN * 4;            // fp32 accumulators of groups 1 .. WK-1 on their way to group 0
-  static constexpr int LDS0 = WK * RING > EPI ? WK * RING : EPI;
-  static constexpr int LDS = LDS0 > RED ? LDS0 : RED;
-  static_assert(LDS <= 160 * 1024, "LDS");
-  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "DMA instructions must divide evenly over the waves");
-  static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % 64 == 0, "wave tile");
-};
-
-template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
-__global__ void __launch_bounds__(128 * WGM * WK, (IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>::LDS * 2 <= 160 * 1024 && BN <= 320 && WK == 1) ? (2 * 2 * WGM / 4) : (2 * WGM * WK / 4))
-igemm_dma_kernel(GemmP p, const half_t* __restrict__ zero_page) {
-  static_assert(BKT == 64 || BKT == 32, "BKT");
-  using GEO = IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>;
-  constexpr int NT = GEO::NT, NW = GEO::NW;
-  constexpr int WM = GEO::WM, WN = GEO::WN, MI = GEO::MI, NI = GEO::NI;
-  constexpr int AV = GEO::AV, WV = GEO::WV, ROWB = GEO::ROWB, STAGE = GEO::STAGE;
-  constexpr int T32 = 32 * ROWB;                       // bytes per 32-row MFMA tile
-  extern __shared__ __attribute__((aligned(1024))) char smem_all[];
-
-  const int tid = threadIdx.x & (NT - 1), lane = tid & 63;                    // thread / wave index inside the k-group
-  const int kgrp = WK == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
-  char* smem_raw = smem_all + kgrp * GEO::RING;                                 // this group's ring
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  // XCD-aware tile order.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with a private L2), so the
-  // launch is 1-D and XCD x takes the x-th contiguous eighth of the tile list.  The list is ordered so that the operand
-  // that is expensive to re-fetch crosses the fabric once: tile_order 0 = n fastest (an XCD owns a band of m-tiles: the
-  // activation is read once, the weight by every XCD), 1 = m fastest (an XCD owns a band of (n, k-split) weight slices:
-  // the weight is read once -- the low-resolution 1280-channel convolutions, where the weight is 10x the activation).
-  int bx, by, bz;
-  {
-    const int T = p.gx * p.gy * p.gz, per = (T + 7) >> 3;
-    const int tix = p.tile_order == 2 ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);   // 2: ablation
-    if (tix >= T) return;
-    if (p.tile_order == 0) { by = tix % p.gy; const int t = tix / p.gy; bx = t % p.gx; bz = t / p.gx; }
-    else { bx = tix % p.gx; const int t = tix / p.gx; by = t % p.gy; bz = t / p.gy; }
-  }
-  const int m0 = bx * BM, n0 = by * BN;
-  const int Cin = p.C1 + p.C2;
-  const int HoWo = p.Ho * p.Wo;
-
-  // ---- DMA lane roles.  A wave-level DMA instruction fills 1 KiB lane-linearly; the (row, chunk) a lane fetches is the
-  // inverse of the swizzled LDS layout:
-  //   BKT = 64: 128-byte rows, byte(R, s) = (R>>4)*2048 + (R&7)*256 + ((R>>3)&1)*128 + ((s ^ (R&7)) * 16)
-  //   BKT = 32:  64-byte rows, byte(R, s) = (R>>4)*1024 + ((R>>2)&3)*256 + (R&3)*64 + ((s ^ ((R>>2)&3)) * 16)
-  // Everything of the gather that does not depend on the k-chunk is precomputed per row; the per-chunk address is pure
-  // arithmetic (no selects that could turn into divergent control flow, no runtime-indexed arrays -> no scratch).
-  int d_row, d_chunk;   // row within the instruction's row group, logical 16-byte chunk
-  if (BKT == 64) {
-    const int line_lo = lane >> 4, half = (lane >> 3) & 1;
-    d_row = half * 8 + line_lo;         // + 4 * (j & 1) added below
-    d_chunk = lane & 7;                 // ^ line below
-  } else {
-    d_row = (lane >> 4) * 4 + ((lane >> 2) & 3);
-    d_chunk = (lane & 3) ^ (lane >> 4);
-  }
-  int a_y0[AV], a_x0[AV], a_bh[AV], a_chunk[AV];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) {
-    const int j = wave * AV + i;
-    int R, ch;
-    if (BKT == 64) { const int line = 4 * (j & 1) + (lane >> 4); R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line; ch = (lane & 7) ^ line; }
-    else { R = j * 16 + d_row; ch = d_chunk; }
-    a_chunk[i] = ch * 8;
-    const int m = m0 + R;
-    int b = m / HoWo;
-    int rr = m - b * HoWo;
-    int yo = rr / p.Wo;
-    int xo = rr - yo * p.Wo;
-    a_bh[i] = b * p.H;
-    a_y0[i] = m < p.M ? yo * p.stride - p.pad : -(1 << 20);   // rows past M fail the bounds test for every tap
-    a_x0[i] = xo * p.stride - p.pad;
-  }
-  const int lim_y = p.ups ? 2 * p.H : p.H, lim_x = p.ups ? 2 * p.W : p.W, ups_sh = p.ups ? 1 : 0;
-  const int nchunks = p.K / BKT;
-  int kc0 = 0, kc1 = nchunks;
-  if (p.splitk > 1) {   // kchunks_per_split is given in 64-wide chunks
-    kc0 = bz * p.kchunks_per_split * (64 / BKT);
-    kc1 = min(nchunks, kc0 + p.kchunks_per_split * (64 / BKT));
-  }
-  int iters = kc1 > kc0 ? kc1 - kc0 : 0;      // loop trips: the same for every k-group (they share the barrier)
-  if (WK > 1) {
-    iters = (iters + WK - 1) / WK;
-    kc0 = min(kc1, kc0 + kgrp * iters);
-    kc1 = min(kc1, kc0 + iters);
-  }
-  // Weight rows: one pointer per DMA instruction, bumped by BKT per chunk.  Rows past N read the zero page, which is as long
-  // as the longest K this kernel is launched with, so they are bumped like the others (no select in the loop).
-  const half_t* w_cur[WV];
-#pragma unroll
-  for (int i = 0; i < WV; ++i) {
-    const int j = wave * WV + i;
-    int R, ch;
-    if (BKT == 64) { const int line = 4 * (j & 1) + (lane >> 4); R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line; ch = (lane & 7) ^ line; }
-    else { R = j * 16 + d_row; ch = d_chunk; }
-    const int n = n0 + R;
-    w_cur[i] = (n < p.N ? p.w + (size_t)n * p.ldw : zero_page) + ch * 8 + kc0 * BKT;
-  }
-
-  // Activation rows: the (tap, source, bounds) part of the gather address changes only when the k-chunk walks into a new
-  // filter tap or from the first concat source into the second; inside a tap consecutive chunks are consecutive channels.
-  // So the full address (bounds test, 64-bit multiply, zero-page select) is rebuilt under a wave-uniform branch on those
-  // boundaries only, and the per-chunk work is one pointer bump per DMA instruction.
-  int is_tap = (kc0 * BKT) / Cin;              // wave-uniform scalars
-  int is_c0 = kc0 * BKT - is_tap * Cin;
-  bool retap = true;
-  const half_t* a_cur[AV];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) a_cur[i] = zero_page;
-
-  auto issue = [&](int buf) {
-    char* sA = smem_raw + buf * STAGE;
-    char* sW = sA + BM * ROWB;
-    if (retap) {
-      int r = 0, s = 0;
-      if (p.ksize == 3) { r = is_tap / 3; s = is_tap - 3 * r; }
-      const half_t* src; int ld, cc;
-      if (is_c0 < p.C1) { src = p.x1; ld = p.ldx1; cc = is_c0; } else { src = p.x2; ld = p.ldx2; cc = is_c0 - p.C1; }
-      const long zoff = zero_page - src;   // element distance to the zero page (plain integer arithmetic on addresses)
-#pragma unroll
-      for (int i = 0; i < AV; ++i) {
-        const int yi = a_y0[i] + r, xi = a_x0[i] + s;
-        const bool ok = (unsigned)yi < (unsigned)lim_y && (unsigned)xi < (unsigned)lim_x;
-        const long off = (long)((a_bh[i] + (yi >> ups_sh)) * p.W + (xi >> ups_sh)) * ld + (cc + a_chunk[i]);
-        const long mask = -(long)ok;                       // all ones when in range: select without control flow
-        a_cur[i] = src + ((off & mask) | ((zoff + a_chunk[i]) & ~mask));
-      }
-      retap = false;
-    }
-    if (ABL != 3 || (is_tap == 0)) {   // ABL 3: the activation operand only for the first filter tap (bound of tap-reuse schemes)
-#pragma unroll
-      for (int i = 0; i < AV; ++i) {
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)a_cur[i], (lds_ptr_t)(sA + (wave * AV + i) * 1024), 16, 0, 0);
-        a_cur[i] += BKT;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)w_cur[i], (lds_ptr_t)(sW + (wave * WV + i) * 1024), 16, 0, 0);
-      w_cur[i] += BKT;
-    }
-    is_c0 += BKT;
-    if (is_c0 >= Cin) { is_c0 = 0; ++is_tap; retap = true; }
-    else if (is_c0 == p.C1) retap = true;
-  };
-
-  // Accumulators.  With alpha == 1 the bias is the accumulator's INITIAL value (p.bias_init, set by the launcher): 4 * NI
-  // unconditional 16-byte loads per lane, issued before the first DMA instruction and landed long before the first MFMA needs
-  // them -- instead of 16 * MI * NI dependent 4-byte loads in the epilogue, each with its own wait, which cost the short-K
-  // layers (10 ... 40 k-chunks per tile) more than their whole main loop.  A lane holds columns n .. n + 3 of every 8-column
-  // group, the same for every mi.
-  floatx16 acc[MI][NI];
-  const float* ebias = p.bias_init ? nullptr : p.bias;   // what the epilogue still has to add
-  if (p.bias_init && kgrp == 0) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
-        floatx4 b = *reinterpret_cast<const floatx4*>(p.bias + min(n, p.N - 4));   // N % 4 == 0: a group is all in or all out
-        if (n >= p.N) b = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][ni][4 * g + j] = b[j];
-      }
-#pragma unroll
-    for (int mi = 1; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[0][ni];
-  } else {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-  }
-
-  // fragment read addressing (same involution as the DMA source permutation)
-  const int lr = lane & 31, hk = lane >> 5;
-  int lane_row_off, xk;
-  if (BKT == 64) { lane_row_off = (lr >> 4) * 2048 + (lr & 7) * 256 + ((lr >> 3) & 1) * 128; xk = lr & 7; }
-  else { lane_row_off = (lr >> 4) * 1024 + ((lr >> 2) & 3) * 256 + (lr & 3) * 64; xk = (lr >> 2) & 3; }
-
-  // NST-deep LDS ring.  Chunk k+NST-1 is issued while chunk k is computed; each wave waits for ITS loads of chunk k with a
-  // counted vmcnt (the newer chunks stay in flight across the barrier), then one raw barrier per chunk makes every wave's
-  // part of chunk k visible and, at the same time, frees the stage that was read in the previous iteration.
-  constexpr int LPS = AV + WV;   // DMA instructions per wave per chunk
-  if (iters > 0) {
-    const int total = kc1 - kc0;   // this group's chunks (<= iters; a short last group idles through its tail but keeps the barrier)
-    int issued = 0;
-#pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-      if (issued < total) { if (ABL != 2) issue(st); ++issued; }
-    int rd = 0, wr = NST - 1;
-    for (int it = 0; it < iters; ++it) {
-      const int ahead = issued - it - 1;           // chunks issued after the one needed now (0 .. NST-2)
-      static_assert((NST - 2) * LPS <= 63, "vmcnt holds 6 bits");
-      if (NST == 2 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else if (ahead == 3 || NST <= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 4 ? 3 : 0) * LPS) : "memory");
-      else if (ahead == 4 || NST <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 5 ? 4 : 0) * LPS) : "memory");
-      else if (ahead == 5 || NST <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 6 ? 5 : 0) * LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST > 7 ? 6 : 0) * LPS) : "memory");
-      __builtin_amdgcn_s_barrier();
-      if (WK > 1 && it >= total) continue;         // wave-uniform: this group has run out of chunks
-      if (ABL == 1) {
-        if (issued < total) { issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
-        rd = rd + 1 == NST ? 0 : rd + 1;
-        continue;
-      }
-      const char* sA = smem_raw + rd * STAGE + (wm0 >> 5) * T32 + lane_row_off;
-      const char* sW = smem_raw + rd * STAGE + BM * ROWB + (wn0 >> 5) * T32 + lane_row_off;
-      // Software pipeline inside the chunk: the fragments of k-step kk+1 are read while the MFMAs of k-step kk run, and the
-      // first k-step's reads are issued BEFORE the next chunk's DMA instructions (their issue slots -- ~100 cycles each -- then
-      // overlap the LDS latency instead of preceding it).  One exposed LDS round trip per chunk instead of one per k-step.
-      constexpr int KS = BKT / 16;
-      half8 wf[2][NI], af[2][MI];
-      auto frag_load = [&](int slot, int kk) {
-        const int ko = ((kk * 2 + hk) ^ xk) * 16;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[slot][mi] = *reinterpret_cast<const half8*>(sA + mi * T32 + ko);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wf[slot][ni] = *reinterpret_cast<const half8*>(sW + ni * T32 + ko);
-      };
-      frag_load(0, 0);
-      if (issued < total) { if (ABL != 2) issue(wr); ++issued; wr = wr + 1 == NST ? 0 : wr + 1; }
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        if (kk + 1 < KS) frag_load((kk + 1) & 1, kk + 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(wf[kk & 1][ni], af[kk & 1][mi], acc[mi][ni]);
-      }
-      rd = rd + 1 == NST ? 0 : rd + 1;
-    }
-  }
-
-  if (WK > 1) {
-    // k-groups 1 .. WK-1 -> group 0, through LDS (the rings are idle: every issued chunk has been waited for and read).  Register r
-    // of lane l of wave w travels as one float at [(g-1)][w][tile][r][l]: lane-contiguous, conflict-free; group 0 adds the groups in
-    // ascending order, so the sum is bit-reproducible.
-    float* sRed = reinterpret_cast<float*>(smem_all);
-    constexpr int PER_WAVE = MI * NI * 16 * 64, PER_GRP = NW * PER_WAVE;
-    __syncthreads();
-    if (kgrp > 0) {
-      float* dst = sRed + (size_t)(kgrp - 1) * PER_GRP + wave * PER_WAVE + lane;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dst[((mi * NI + ni) * 16 + r) * 64] = acc[mi][ni][r];
-    }
-    __syncthreads();
-    if (kgrp > 0) return;              // whole waves exit: s_barrier counts the surviving waves only
-#pragma unroll
-    for (int g = 1; g < WK; ++g) {
-      const float* src = sRed + (size_t)(g - 1) * PER_GRP + wave * PER_WAVE + lane;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * NI + ni) * 16 + r) * 64];
-    }
-    smem_raw = smem_all;               // the epilogue stages from the start of LDS
-  }
-
-  if (p.epi_lds && p.splitk <= 1) {
-    // Coalesced epilogue: the output tile is assembled in LDS (the ring is idle now) and written as full rows, 16 bytes per
-    // lane.  The residual tile is staged the same way, so out = fp16(alpha*acc + bias + residual) with a single rounding.
-    // EPASS passes of EROWS rows (pass e = the waves of wave-row e when the tile is staged in parts).  Store loop: thread t owns
-    // the fixed 16-byte vector v = t % VPR of row group g = t / VPR and walks rows g, g + G, ...: per-channel sums for the
-    // GroupNorm that consumes this tensor fall out of it (fp32 sums of the rounded fp16 values the consumer will read), and every
-    // partial is combined in a FIXED order (rows ascending per thread, then groups ascending): bit-reproducible statistics.
-    constexpr int OLD = GEO::OLD, VPR = GEO::VPR, G = GEO::G, EPASS = GEO::EPASS, EROWS = GEO::EROWS;
-    half_t* sOut = reinterpret_cast<half_t*>(smem_raw);
-    const bool tr_tile = p.outT != nullptr && n0 >= p.vt_col0;      // block-uniform (the launcher aligns vt_col0 to the tile width)
-    const int sv = tid % VPR, sg = tid / VPR;
-    const bool s_active = sg < G;
-    float cs[8], cq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EPASS; ++e) {
-      const int r0 = e * EROWS;                         // first tile row of this pass
-      const bool res_staged = p.res && !p.res_late;
-      if (res_staged) {
-        if (s_active) {
-          // clamped addresses instead of predicated loads: the loads of an unrolled group issue back to back (rows past M / columns
-          // past N stage finite junk that is never stored)
-          const int nres = min(n0 + sv * 8, p.N - 8);
-#pragma unroll 8
-          for (int r = sg; r < EROWS; r += G) {
-            const int m = min(m0 + r0 + r, p.M - 1);
-            *reinterpret_cast<half8*>(sOut + r * OLD + sv * 8) = ldg_half8(p.res + (size_t)m * p.ldres + nres);
-          }
-        }
-        __syncthreads();
-      }
-      if (tr_tile) {
-        // V^T-style output (columns >= vt_col0 are written transposed per batch item): the tile is staged TRANSPOSED, [BN][EROWS + 8],
-        // and leaves as 16-byte runs of 8 consecutive tokens of one output channel
-        constexpr int TOLD = GEO::TOLD, VPT = EROWS / 8;
-        if (EPASS == 1 || (wave >> 1) == e) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const int ml = wm0 - r0 + mi * 32 + (lane & 31);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int nl = wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  float o = acc[mi][ni][4 * g + j] * p.alpha;
-                  if (ebias && n0 + nl + j < p.N) o += ebias[n0 + nl + j];
-                  sOut[(nl + j) * TOLD + ml] = (half_t)o;
-                }
-              }
-            }
-          }
-        }
-        __syncthreads();
-        const int ncol = p.N - p.vt_col0;
-        for (int idx = tid; idx < BN * VPT; idx += NT) {
-          const int nl = idx / VPT, v = idx - nl * VPT;
-          const int n = n0 + nl, m = m0 + r0 + v * 8;
-          if (n < p.N && m < p.M) {
-            const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
-            half_t* dst = (half_t*)p.outT + ((size_t)b * ncol + (n - p.vt_col0)) * p.vt_ld + tok;
-            *reinterpret_cast<half8*>(dst) = *reinterpret_cast<const half8*>(sOut + nl * TOLD + v * 8);
-          }
-        }
-        if (e + 1 < EPASS) __syncthreads();
-        continue;
-      }
-      if (EPASS == 1 || (wave >> 1) == e) {
-        // two copies, selected by a block-uniform branch: with the bias already in the accumulators (the usual case) the staging
-        // loop has no per-element control flow at all
-        auto stage = [&](auto has_bias) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const int ml = wm0 - r0 + mi * 32 + (lane & 31);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              half4* slot0 = reinterpret_cast<half4*>(sOut + ml * OLD + wn0 + ni * 32 + 4 * (lane >> 5));   // slot of group g: + 2 * g
-              half4 r4[4];
-              if (res_staged) {                  // the four residual slots of this 32-column tile in flight together
-#pragma unroll
-                for (int g = 0; g < 4; ++g) r4[g] = slot0[2 * g];
-              }
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
-                float o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  o[j] = acc[mi][ni][4 * g + j] * p.alpha;
-                  if constexpr (decltype(has_bias)::value) { if (n + j < p.N) o[j] += ebias[n + j]; }
-                }
-                if (res_staged) {
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) o[j] += (float)r4[g][j];
-                }
-                half4 h4 = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-                slot0[2 * g] = h4;
-              }
-            }
-          }
-        };
-        if (ebias) stage(std::true_type{}); else stage(std::false_type{});
-      }
-      __syncthreads();
-      if (!p.geglu) {
-        const int n = n0 + sv * 8;
-        if (s_active && n < p.N) {
-#pragma unroll 4
-          for (int r = sg; r < EROWS; r += G) {
-            const int m = m0 + r0 + r;
-            half8 val = *reinterpret_cast<const half8*>(sOut + r * OLD + sv * 8);
-            if (m < p.M) {
-              if (p.res && p.res_late) {   // residual added on the way out (coalesced 16-byte reads, no staging pass / barrier)
-                const half8 rv = ldg_half8(p.res + (size_t)m * p.ldres + n);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) val[j] = (half_t)((float)val[j] + (float)rv[j]);
-              }
-              *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = val;
-              if (p.stats) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { float f = (float)val[j]; cs[j] += f; cq[j] += f * f; }
-              }
-            }
-          }
-        }
-      } else {
-        // columns come in [x(32) | gate(32)] groups; the block's BN columns hold BN/2 outputs starting at column n0/2
-        constexpr int VPO = BN / 16;
-        for (int idx = tid; idx < EROWS * VPO; idx += NT) {
-          const int r = idx / VPO, v = idx - r * VPO;
-          const int m = m0 + r0 + r;
-          const int xc = (v >> 2) * 64 + (v & 3) * 8;     // local column of the x vector; its gate sits 32 columns further
-          const int no = (n0 >> 1) + v * 8;
-          if (m < p.M && no < (p.N >> 1)) {
-            half8 x = *reinterpret_cast<const half8*>(sOut + r * OLD + xc);
-            half8 gt = *reinterpret_cast<const half8*>(sOut + r * OLD + xc + 32);
-            half8 o8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o8[j] = (half_t)((float)x[j] * gelu_f((float)gt[j]));
-            *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + no) = o8;
-          }
-        }
-      }
-      if (e + 1 < EPASS) __syncthreads();               // the next pass overwrites the staging rows
-    }
-    if (p.stats && !p.geglu) {
-      float* sSt = reinterpret_cast<float*>(sOut + EROWS * OLD);       // [G][BN][2]
-      if (s_active) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sSt[(sg * BN + sv * 8 + j) * 2 + 0] = cs[j];
-          sSt[(sg * BN + sv * 8 + j) * 2 + 1] = cq[j];
-        }
-      }
-      __syncthreads();
-      for (int c = tid; c < BN; c += NT) {
-        if (n0 + c < p.N) {
-          float s = 0.f, q = 0.f;
-#pragma unroll
-          for (int g = 0; g < G; ++g) { s += sSt[(g * BN + c) * 2]; q += sSt[(g * BN + c) * 2 + 1]; }
-          float* dst = p.stats + ((size_t)bx * p.N + n0 + c) * 2;
-          dst[0] = s;
-          dst[1] = q;
-        }
-      }
-    }
-    return;
-  }
-
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm0 + mi * 32 + (lane & 31);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nb = n0 + wn0 + ni * 32 + 8 * g + 4 * (lane >> 5);
-        float v[4] = {acc[mi][ni][4 * g + 0], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-        if (p.splitk > 1) {
-          if (m < p.M) {
-            float* dst = p.slab + ((size_t)bz * p.M + m) * p.N + nb;
-            if (nb + 3 < p.N) *reinterpret_cast<floatx4*>(dst) = floatx4{v[0], v[1], v[2], v[3]};
-            else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (nb + j < p.N) dst[j] = v[j];
-            }
-          }
-        } else {
-          epilogue_store4(p, m, nb, v, ebias);
-        }
-      }
-    }
-  }
-}
-
-static int g_last_geom[7] = {0, 0, 0, 0, 0, 0, 0};   // template arguments of the most recent igemm_dma_kernel launch (all 0: the v1 kernel)
+static thread_local int g_last_geom[7] = {0, 0, 0, 0, 0, 0, 0};   // template arguments of the most recent igemm_dma_kernel launch (all 0: the v1 kernel)
 template <int BM, int BN, int BKT, int NST, int WGM = 2, int ABL = 0, int WK = 1>
 static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t* zero_page) {
   using GEO = IgemmGeom<BM, BN, BKT, NST, WGM, ABL, WK>;
@@ -833,10 +295,8 @@ static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t
   const int total = (int)(grid.x * grid.y * grid.z);
   grid = dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
   constexpr int lds = GEO::LDS;
-  static unsigned long long attr_devs = 0;
-  if (first_on_device(attr_devs)) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  }
+  static DeviceOnce attr_once;
+  if (int r = once_per_device(attr_once, [&]() { return (int)hipFuncSetAttribute((const void*)igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); })) return r;
   igemm_dma_kernel<BM, BN, BKT, NST, WGM, ABL, WK><<<grid, GEO::NT_ALL, lds, st>>>(p, zero_page);
   return 0;
 }
@@ -905,8 +365,9 @@ static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
 static int g_bias_init = 1;     // 0: bias added in the epilogue (ablation)
+static int g_sched = 0;         // tuning "igemm_sched" = 1: the hand-scheduled main loop (igemm_dma_kernel<..., ABL = 4>) for the one-k-group tile configurations
 static int g_force_split = 0;   // > 0 with igemm_force_cfg: split-K of every auto-configured launch (in-forward tuning sweeps)
-static int g_last_cfg = -1, g_last_split = 1;   // what the most recent launch_igemm used (profiling dumps)
+static thread_local int g_last_cfg = -1, g_last_split = 1;   // per thread: two contexts may launch from two threads   // what the most recent launch_igemm used (profiling dumps)
 void igemm_last_launch(int* cfg, int* split, int* geom) { *cfg = g_last_cfg; *split = g_last_split; for (int i = 0; i < 7; ++i) geom[i] = g_last_geom[i]; }
 static int g_force_cfg = -1;   // >= 0: every auto-configured launch uses this tile configuration (tests, whole-forward A/B)
 static int g_var128 = 2, g_var64 = 0, g_var256 = 0, g_var320 = 1, g_var256n = 1;
@@ -915,7 +376,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_sched", &g_sched}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -984,6 +445,9 @@ int igemm_table_lookup(int M, int N, int K, int ks, int* cfg, int* split, int* e
 // cfg 6 = 256x320, 7 = 256x256 (8 waves, 128-byte rows, two stages, one block per CU); 8-11: K-parallel wave groups; 12 = 64x320;
 // 13 = 128x128 with a two-stage ring; 14 / 15 = 128x128 / 128x256 with 128-byte rows: reached through the table or force_cfg
 
+// product tile configurations with one k-group: compiler-scheduled main loop, or (tuning "igemm_sched") the hand-scheduled one
+#define LDMA(...) (g_sched == 1 ? launch_dma<__VA_ARGS__, 2, 4>(p, grid, st, g_zero_page) : g_sched == 2 ? launch_dma<__VA_ARGS__, 2, 5>(p, grid, st, g_zero_page) : launch_dma<__VA_ARGS__>(p, grid, st, g_zero_page))
+#define LDMA0(...) launch_dma<__VA_ARGS__>(p, grid, st, g_zero_page)
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used,
                  int* stats_tile_rows) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -2;
@@ -1093,22 +557,22 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (cfg == 3) {
     r = g_var256 == 1 ? launch_dma<256, 128, 32, 2, 2>(p, grid, st, g_zero_page) : launch_dma<256, 128, 32, 3, 2>(p, grid, st, g_zero_page);
   } else if (cfg == 4) {
-    if (sparse == 2 && g_var320 == 1) r = launch_dma<128, 320, 32, 5>(p, grid, st, g_zero_page);
+    if (sparse == 2 && g_var320 == 1) r = LDMA0(128, 320, 32, 5);
     else switch (g_var320) {
-      case 0: r = launch_dma<128, 320, 32, 3>(p, grid, st, g_zero_page); break;       // 84 KB ring = whole-tile epilogue, 1 block / CU
-      case 2: r = launch_dma<128, 320, 64, 2>(p, grid, st, g_zero_page); break;       // 128-byte rows, 112 KB, 1 block / CU
+      case 0: r = LDMA0(128, 320, 32, 3); break;       // 84 KB ring = whole-tile epilogue, 1 block / CU
+      case 2: r = LDMA0(128, 320, 64, 2); break;       // 128-byte rows, 112 KB, 1 block / CU
       case 11: r = launch_dma<128, 320, 32, 2, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
       case 12: r = launch_dma<128, 320, 32, 2, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
-      default: r = launch_dma<128, 320, 32, 2>(p, grid, st, g_zero_page); break;      // 56 KB ring, two-pass epilogue, 2 blocks / CU
+      default: r = LDMA(128, 320, 32, 2); break;      // 56 KB ring, two-pass epilogue, 2 blocks / CU
     }
   } else if (cfg == 12) {
-    r = launch_dma<64, 320, 32, 2>(p, grid, st, g_zero_page);             // 64 x 320: 768 tiles on the 12-row 64 x 64 level = 3 per CU
+    r = LDMA0(64, 320, 32, 2);             // 64 x 320: 768 tiles on the 12-row 64 x 64 level = 3 per CU
   } else if (cfg == 13) {
-    r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page);            // 32 KB ring (two-pass epilogue): 4 blocks / CU for the short-K layers
+    r = LDMA(128, 128, 32, 2);            // 32 KB ring (two-pass epilogue): 4 blocks / CU for the short-K layers
   } else if (cfg == 14) {
-    r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page);            // 128-byte rows, half the barriers per k: 64 KB, 2 blocks / CU
+    r = LDMA(128, 128, 64, 2);            // 128-byte rows, half the barriers per k: 64 KB, 2 blocks / CU
   } else if (cfg == 15) {
-    r = launch_dma<128, 256, 64, 2>(p, grid, st, g_zero_page);            // the same for the 128 x 256 tile: 96 KB, 1 block / CU
+    r = LDMA0(128, 256, 64, 2);            // the same for the 128 x 256 tile: 96 KB, 1 block / CU
   } else if (cfg == 8) {
     r = launch_dma<64, 64, 64, 2, 2, 0, 4>(p, grid, st, g_zero_page);      // 16 waves: 4 k-groups
   } else if (cfg == 11) {
@@ -1122,11 +586,11 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (cfg == 7) {
     r = launch_dma<256, 256, 64, 2, 4>(p, grid, st, g_zero_page);
   } else if (cfg == 5) {
-    if (sparse == 2 && g_var256n == 1) r = launch_dma<128, 256, 32, 6>(p, grid, st, g_zero_page);
+    if (sparse == 2 && g_var256n == 1) r = LDMA0(128, 256, 32, 6);
     else switch (g_var256n) {
-      case 0: r = launch_dma<128, 256, 32, 3>(p, grid, st, g_zero_page); break;       // 72 KB, 2 blocks / CU
-      case 2: r = launch_dma<128, 256, 64, 2>(p, grid, st, g_zero_page); break;
-      default: r = launch_dma<128, 256, 32, 2>(p, grid, st, g_zero_page); break;      // 48 KB: two-pass epilogue, 3 blocks / CU by LDS
+      case 0: r = LDMA0(128, 256, 32, 3); break;       // 72 KB, 2 blocks / CU
+      case 2: r = LDMA0(128, 256, 64, 2); break;
+      default: r = LDMA(128, 256, 32, 2); break;      // 48 KB: two-pass epilogue, 3 blocks / CU by LDS
     }
   } else if (cfg == 0) {
     int var = g_var128;
@@ -1136,26 +600,26 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     if (var == 2 && sparse == 2) var = 8;
     else if (var == 2 && sparse == 1) var = 3;
     switch (var) {
-      case 1: r = launch_dma<128, 128, 64, 3>(p, grid, st, g_zero_page); break;
-      case 2: r = launch_dma<128, 128, 32, 3>(p, grid, st, g_zero_page); break;
-      case 3: r = launch_dma<128, 128, 32, 4>(p, grid, st, g_zero_page); break;
-      case 4: r = launch_dma<128, 128, 32, 2>(p, grid, st, g_zero_page); break;
-      case 8: r = launch_dma<128, 128, 32, 8>(p, grid, st, g_zero_page); break;       // 128 KB ring: sparse launches
+      case 1: r = LDMA0(128, 128, 64, 3); break;
+      case 2: r = LDMA(128, 128, 32, 3); break;
+      case 3: r = LDMA0(128, 128, 32, 4); break;
+      case 4: r = LDMA(128, 128, 32, 2); break;
+      case 8: r = LDMA0(128, 128, 32, 8); break;       // 128 KB ring: sparse launches
       case 11: r = launch_dma<128, 128, 32, 3, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
       case 12: r = launch_dma<128, 128, 32, 3, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
       case 15: r = launch_dma<128, 128, 32, 3, 2, 3>(p, grid, st, g_zero_page); break;   // ablation: activation loads for tap 0 only
-      default: r = launch_dma<128, 128, 64, 2>(p, grid, st, g_zero_page); break;
+      default: r = LDMA(128, 128, 64, 2); break;
     }
   } else {
     int v64 = g_var64;
     if (v64 == 0 && sparse == 2) v64 = 8;
     else if (v64 == 0 && sparse == 1) v64 = 2;
     switch (v64) {
-      case 8: r = launch_dma<64, 64, 64, 8>(p, grid, st, g_zero_page); break;         // 128 KB ring: sparse launches
-      case 1: r = launch_dma<64, 64, 64, 2>(p, grid, st, g_zero_page); break;
-      case 2: r = launch_dma<64, 64, 64, 4>(p, grid, st, g_zero_page); break;
-      case 3: r = launch_dma<64, 64, 32, 4>(p, grid, st, g_zero_page); break;
-      default: r = launch_dma<64, 64, 64, 3>(p, grid, st, g_zero_page); break;
+      case 8: r = LDMA0(64, 64, 64, 8); break;         // 128 KB ring: sparse launches
+      case 1: r = LDMA0(64, 64, 64, 2); break;
+      case 2: r = LDMA0(64, 64, 64, 4); break;
+      case 3: r = LDMA0(64, 64, 32, 4); break;
+      default: r = LDMA(64, 64, 64, 3); break;
     }
   }
   if (r) return r;

@@ -252,11 +252,13 @@ static bool gn_small_ok(int C1, int C2, int HW, int G) {
 static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                            const float* beta, int silu, half_t* out, hipStream_t st) {
   const int cpg = (C1 + C2) / G;
-  static unsigned long long attr_devs = 0;
-  if (first_on_device(attr_devs)) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2 + 8192));
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gn_small_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2 + 8192));
-  }
+  static DeviceOnce attr_once;
+  // the launch asks for HW * cpg * 2 + cpg * 8 + 16 bytes (slice + gamma / beta + alignment slack): <= gn_small_max() * 2 + 8192 + 16
+  if (int r = once_per_device(attr_once, [&]() {
+        const int lim = gn_small_max() * 2 + 8192 + 16;
+        int e = (int)hipFuncSetAttribute((const void*)gn_small_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        return e ? e : (int)hipFuncSetAttribute((const void*)gn_small_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+      })) return r;
   // 1024-thread blocks: each (sample, group) slice is a latency chain load -> reduce -> normalise -> store, and four times
   // the lanes per slice shorten it at every row count measured (1 row: 16.2 -> 12.7 us per launch; 12 rows: 23.0 -> 20.7)
   static const int wide_below = getenv("PNPI_GN_WIDE_BELOW") ? atoi(getenv("PNPI_GN_WIDE_BELOW")) : (1 << 30);

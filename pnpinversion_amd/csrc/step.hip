@@ -196,8 +196,8 @@ int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_
   int npow2 = 1;
   while ((size_t)npow2 < n) npow2 <<= 1;
   if (npow2 > 32768) return -6;
-  static unsigned long long attr_devs = 0;
-  if (first_on_device(attr_devs)) (void)hipFuncSetAttribute((const void*)quantile_abs_diff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+  static DeviceOnce attr_once;
+  if (int r = once_per_device(attr_once, [&]() { return (int)hipFuncSetAttribute((const void*)quantile_abs_diff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4); })) return r;
   quantile_abs_diff_kernel<<<nimg, 1024, (size_t)npow2 * sizeof(float), st>>>(eps, rows_per_img, row_elems, q, npow2, thr_out);
   return (int)hipGetLastError();
 }

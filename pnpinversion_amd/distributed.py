@@ -3,8 +3,17 @@
 The hot path shards embarrassingly (one image = one independent unit): rank r takes items r, r + W, ...; the only
 collective is one broadcast of the packed weight arena at start-up, so that only rank 0 has to read / generate weights."""
 import os
+import time
 
 import torch
+
+
+def prepare_env():
+    """Environment every multi-process GPU launch needs on this driver stack, set before torch.distributed / RCCL initialise:
+    dmabuf IPC (the host driver has no legacy IPC: without it RCCL fails with `hipIpcGetMemHandle: invalid argument`) and a
+    rendezvous address that resolves (the container hostname may not)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 
 class _DevView:
@@ -28,13 +37,18 @@ def broadcast_buffer(t, src=0, group=None, chunk_bytes=1 << 30):
     return n
 
 
-def broadcast_weights(engine, src=0, group=None):
-    """RCCL broadcast of the whole packed arena from `src`; receivers mark their weight slots loaded."""
+def broadcast_weights(engine, src=0, group=None, stats=None):
+    """RCCL broadcast of the whole packed arena from `src`; receivers mark their weight slots loaded.  stats (dict, optional)
+    receives {"bytes", "ms", "ranks"}: the one collective of the path, timed between device synchronisations on this rank (the first
+    call also pays RCCL's communicator set-up)."""
     import torch.distributed as dist
     t = arena_tensor(engine)
     torch.cuda.synchronize(engine.device)
+    t0 = time.perf_counter()
     n = broadcast_buffer(t, src=src, group=group)
     torch.cuda.synchronize(engine.device)
+    if stats is not None:
+        stats.update(bytes=int(n), ms=(time.perf_counter() - t0) * 1e3, ranks=dist.get_world_size(group))
     if dist.get_rank(group) != src:
         engine.mark_all_loaded()
     return n

@@ -4,6 +4,9 @@
       P2PEditor("directinversion+p2p") run at 2 + 2 steps with Refine + Reweight + LocalBlend (tests/golden/e2e_sd1.npz, made by
       oracle/make_golden.py from the unmodified reference modules): inversion latents, offsets, reconstruction / edited latents and
       the decoded panels through pnpi_ddim_invert / pnpi_direct_edit / P2PEditor;
+  (a2) the same at the benchmarked SCHEDULE: full width, 50 + 50 steps, against the reference's own run (tests/golden/e2e_sd1_50.npz) --
+      this is also the long-schedule check of the 64 x 64 (4096-token) attention sites, which the reduced 50-step configurations below
+      leave out; measured on MI355X: inversion <= 2.0e-3 at every sampled step, offsets <= 1.7e-3, edited latents 4.9e-3, panels 58 / 52 dB;
   (b) the FULL 50 + 50-step schedule with its real tables (51-row cross_replace_alpha, LocalBlend from step 10, self-attention
       window 0..30) on the reduced-width configurations against the CPU oracle, asserting the tolerances SURVEY.md 8(d) states for
       50 + 50 steps -- final latents rel-L2 <= 2e-2, decoded images PSNR >= 35 dB (and mean |diff| <= 2/255) -- and logging the
@@ -103,6 +106,60 @@ def test_sd1_full_width_loops_and_editor_against_reference_golden():
     assert d_rec <= 2.0 and d_edit <= 2.0, (d_rec, d_edit)               # decoded pixels mean |diff| <= 2/255
     assert ps_rec >= 35.0 and ps_edit >= 35.0, (ps_rec, ps_edit)         # PSNR(native, reference) >= 35 dB
     eng.close()
+
+
+# ------------------------------------------------------------------------- (a2) full SD-1.x width AND the full 50 + 50-step schedule
+def _subsampled_stage_errors(st, g, steps):
+    xs = torch.stack([x.cpu() for x in st["x_stars"]])
+    nl = torch.stack([x.cpu() for x in st["noise_loss_list"]])
+    xi, ni = [int(i) for i in g["x_stars_index"]], [int(i) for i in g["noise_loss_index"]]
+    gx, gn = torch.from_numpy(g["x_stars"]), torch.from_numpy(g["noise_loss"])
+    inv = {k: rel(xs[k], gx[j]) for j, k in enumerate(xi)}
+    # an offset is a small difference of two latents: its error is measured against the latent it corrects (x*_{t-1}), as in the other loops
+    off = {k: ((nl[k] - gn[j]).norm() / xs[steps - k - 1].norm().clamp_min(1e-9) / 2 ** 0.5).item() for j, k in enumerate(ni)}
+    return inv, off
+
+
+def test_sd1_full_width_full_schedule_against_reference_golden():
+    """The benchmarked configuration at the benchmarked schedule: the reference's own P2PEditor("directinversion+p2p") at full SD-1.x
+    width, 50 + 50 steps, Refine + Reweight + LocalBlend (tests/golden/e2e_sd1_50.npz: 63 min of the build container's CPU, every 10th
+    inversion latent / offset kept) against the product's P2PEditor on the same image, prompts and weights.  Bars: SURVEY 8(d)."""
+    g = np.load(os.path.join(GOLD, "e2e_sd1_50.npz"))
+    cfg, steps = SD1, int(g["steps"])
+    assert steps == 50
+    pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    seed = int(g["weight_seed"])
+    pipe.load_state_dict(weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed))
+    src, tgt = str(g["src"]), str(g["tgt"])
+    w0, w1 = [str(x) for x in g["blend"]]
+    ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=pipe)
+    panel, st = ed.edit_image_directinversion(_cat_image(), src, tgt, guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
+                                              blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)}, return_stages=True)
+    inv, off = _subsampled_stage_errors(st, g, steps)
+    rec, out = st["reconstruct_latent"].cpu(), st["latents"].cpu()
+    g_rec, g_out = torch.from_numpy(g["reconstruct_latent"]), torch.from_numpy(g["edited_latents"])
+    r_src = rel(out[0], g_out[0])
+    r_rec = rel(rec[1], g_rec[1])
+    scale = max(1.0, float(g_out[1].pow(2).mean().sqrt()))
+    r_out, frac = masked_rel(out[1], g_out[1], pix_tol=0.25 * scale)
+    p = np.array(panel)
+    rec_small, edit_small = p[::4, 1024:1536:4], p[::4, 1536::4]
+    d = [float(np.abs(a.astype(np.int32) - b.astype(np.int32)).mean()) for a, b in ((rec_small, g["recon_image_small"]), (edit_small, g["edited_image_small"]))]
+    ps = [float(psnr_u8(rec_small, g["recon_image_small"])), float(psnr_u8(edit_small, g["edited_image_small"]))]
+    rep = {"inversion_rel_l2_at_step": inv, "offset_abs_err_over_latent_norm_at_step": off, "final_source_rel_l2": r_src,
+           "final_reconstruction_target_rel_l2": r_rec, "final_edit_rel_l2": rel(out[1], g_out[1]), "final_edit_rel_l2_outside_localblend_flips": r_out,
+           "localblend_mask_flip_fraction": frac, "edit_latent_rms": scale, "panel_mean_abs_diff": d, "panel_psnr_db": ps}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "drift_sd1_full_width_50.json"), "w"), indent=1)
+    print("sd1 full width 50+50 vs the reference:", json.dumps(rep))
+    for k, r in inv.items():
+        assert r < 4e-3 * max(k, 1) ** 0.5, (k, r)                       # DDIM latents after k steps: <= 4e-3 sqrt(k)
+    assert max(off.values()) < 2e-2, off
+    assert r_src < 2e-2, r_src                                           # direct inversion: the source branch returns to x*_0
+    assert r_rec < 2e-2, r_rec
+    assert frac <= 0.005 and r_out < 2e-2, (r_out, frac)                 # SURVEY 8(d): final latents after 50 + 50 steps
+    assert max(d) <= 2.0 and min(ps) >= 35.0, (d, ps)                    # SURVEY 8(d): decoded pixels
+    pipe.engine.close()
 
 
 # ----------------------------------------------------------------------------------------------- (b) 50 + 50 steps vs the oracle
@@ -226,11 +283,11 @@ def test_full_50_step_schedule_against_oracle(name):
     assert r_rec < 2e-2, r_rec
     assert torch.equal(rec[0], out[0])
     assert d[0] <= 2.0 and ps[0] >= 35.0, (d, ps)
-    # The controller-edited target row gets the same bar wherever the branch is conditioned well enough for it to be meaningful;
-    # where the fp32 oracle itself moves by more than 2e-2 under one fp16 rounding per step, the HIP path must stay within THAT.
+    # The controller-edited target row: the same stated bars, asserted as stated.  (The conditioning figures above -- the fp32 oracle
+    # re-run with one fp16 rounding per step -- are computed only when a bar is missed and are diagnostics in the drift file, not a bar.)
     assert frac <= 0.005, frac
-    assert r_out < 2e-2 or r_out < cond, (r_out, cond)
-    assert ps[1] >= 35.0 or ps[1] >= ps_cond, (ps, ps_cond)
+    assert r_out < 2e-2, (r_out, cond)
+    assert ps[1] >= 35.0 and d[1] <= 2.0, (ps, d, ps_cond)
     eng.close()
 
 
