@@ -93,7 +93,59 @@ class AttentionControl(abc.ABC):
 
 class AttentionStore(AttentionControl):
     """AttentionStore (attention_control.py:214-248) has no effect on the denoised latents; natively it is a plain forward.
-    (The only stored maps ever consumed are LocalBlend's five 16x16 cross maps, which the edit kernel accumulates itself.)"""
+    (The only stored maps ever consumed are LocalBlend's five 16x16 cross maps, which the edit kernel accumulates itself.)
+
+    keep_maps=True (opt-in; visualisation callers of the reference read them): the controller runs through the call-back path instead
+    -- the probabilities of every attention site are materialised and this object is called on them exactly as the reference's is
+    (:178-190) -- and `attention_store` / `get_average_attention()` hold the conditional-half maps of the <= 32^2-token sites, summed
+    over steps (:221-239).  Slow (no flash attention, one host round trip per site)."""
+
+    def __init__(self, keep_maps=False):
+        super().__init__()
+        self.keep_maps = bool(keep_maps)
+        self._pnpi_force_callback = self.keep_maps
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+
+    @staticmethod
+    def get_empty_store():
+        return {"down_cross": [], "mid_cross": [], "up_cross": [], "down_self": [], "mid_self": [], "up_self": []}
+
+    def forward(self, attn, is_cross, place_in_unet):
+        key = f"{place_in_unet}_{'cross' if is_cross else 'self'}"
+        if attn.shape[1] <= 32 ** 2:      # avoid memory overhead (:224)
+            self.step_store[key].append(attn.clone())       # the engine re-uses the buffer behind `attn` at the next site
+        return attn
+
+    def __call__(self, attn, is_cross, place_in_unet):
+        """AttentionControl.__call__ (:178-190, LOW_RESOURCE False): `forward` sees the conditional half; 32 sites make a step."""
+        h = attn.shape[0]
+        attn[h // 2:] = self.forward(attn[h // 2:], is_cross, place_in_unet)
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            self.between_steps()
+        return attn
+
+    def between_steps(self):
+        if not self.keep_maps:
+            return
+        if len(self.attention_store) == 0:
+            self.attention_store = self.step_store
+        else:
+            for key in self.attention_store:
+                for i in range(len(self.attention_store[key])):
+                    self.attention_store[key][i] += self.step_store[key][i]
+        self.step_store = self.get_empty_store()
+
+    def get_average_attention(self):
+        return {key: [item / self.cur_step for item in self.attention_store[key]] for key in self.attention_store}
+
+    def reset(self):
+        super().reset()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
 
 
 class AttentionControlEdit(AttentionStore, abc.ABC):
@@ -201,7 +253,9 @@ def is_callback_controller(controller):
     """A controller object of the reference's protocol (models/p2p/attention_control.py:151-190: `controller(attn, is_cross,
     place_in_unet)` at every attention site) for which the library has no kernel descriptor: it runs through the
     materialise-and-call-back path of pnpi_set_attention_callback (slow, exact semantics)."""
-    return controller is not None and not hasattr(controller, "tables") and callable(controller)
+    if controller is None or not callable(controller):
+        return False
+    return getattr(controller, "_pnpi_force_callback", False) or not hasattr(controller, "tables")
 
 
 class ForeignControllerAdapter:
@@ -258,9 +312,7 @@ def adapt_foreign_controller(controller):
       * this module's own classes: unchanged (they carry `.tables()`);
       * the reference's AttentionReplace / Refine / Reweight WITHOUT LocalBlend: the kernel descriptor read off their attributes;
       * anything else callable (LocalBlend needs the stored 16 x 16 maps; user subclasses): the call-back path, exact and slow."""
-    if controller is None or hasattr(controller, "tables"):
-        return controller
-    if getattr(controller, "_pnpi_force_callback", False):
+    if controller is None or getattr(controller, "_pnpi_force_callback", False) or hasattr(controller, "tables"):
         return controller
     name = type(controller).__name__
     if name in ("DummyController", "EmptyControl"):

@@ -6,7 +6,7 @@ Faithful schedule: 50 B=1 UNet calls (ddim_loop, :308-319) + 50 B=4 calls (offse
 VAE decode whose result the reference's caller throws away (:357).  Each phase is ONE C-ABI call; no host round trip per step."""
 import torch
 
-from ..utils.utils import image2latent, latent2image
+from ..utils.utils import image2latent, latent2image, slerp_tensor
 from .attention_control import register_attention_control
 
 
@@ -235,6 +235,6 @@ class NegativePromptInversion(_SinglePromptInversion):
         register_attention_control(self.model, None)
         image_rec, ddim_latents, image_rec_latent = self.ddim_inversion(image_gt)
         uncond, cond = self.context.chunk(2)
-        if npi_interp > 0.0:
-            raise NotImplementedError("npi_interp > 0 (slerp between the embeddings) is not built; P2PEditor never passes it")
+        if npi_interp > 0.0:     # inversion.py:98-99: vector interpolation between the conditional and the unconditional embedding
+            cond = slerp_tensor(npi_interp, cond, uncond)
         return image_rec, image_rec_latent, ddim_latents, [cond] * self.num_ddim_steps

@@ -28,6 +28,21 @@ def load_512(image_path, left=0, right=0, top=0, bottom=0):
     return np.array(Image.fromarray(image).resize((512, 512)))
 
 
+def slerp(val, low, high):
+    """utils/utils.py:7-16: spherical interpolation between the rows of two [n, d] tensors"""
+    low_norm = low / torch.norm(low, dim=1, keepdim=True)
+    high_norm = high / torch.norm(high, dim=1, keepdim=True)
+    omega = torch.acos((low_norm * high_norm).sum(1))
+    so = torch.sin(omega)
+    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+
+
+def slerp_tensor(val, low, high):
+    """utils/utils.py:19-25 (negative-prompt inversion's npi_interp): slerp of the flattened tensors"""
+    shape = low.shape
+    return slerp(val, low.flatten(1), high.flatten(1)).reshape(shape)
+
+
 def init_latent(latent, model, height, width, generator, batch_size):
     """utils/utils.py:48-55"""
     if latent is None:

@@ -1,6 +1,8 @@
 """The N > 1 path on CPU (gloo, world_size 2): static image sharding and the start-up weight-buffer broadcast
 (on the GPU box the same code runs over RCCL / xGMI with the packed weight arena as the buffer)."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -56,8 +58,9 @@ def test_single_rank_is_identity():
     assert shard_items(list(range(5)), rank=0, world=1) == list(range(5))
 
 
-def test_bench_self_spawns_its_ranks():
-    """`python bench.py --gpus 2 ...` without a launcher starts its own two ranks under torch.distributed.run (the driver's N > 1
+@pytest.mark.parametrize("n,steps,warmup", [(2, 3, 1), (8, 20, 5)])
+def test_bench_self_spawns_its_ranks(n, steps, warmup):
+    """`python bench.py --gpus N ...` (N = 2, and the driver's 8-GPU command line `--gpus 8 --steps 20 --warmup 5`) without a launcher starts its own two ranks under torch.distributed.run (the driver's N > 1
     command form is a plain python call): rendezvous on 127.0.0.1, barrier, max-over-ranks, ONE JSON line from rank 0.  --dry-run
     keeps it on the CPU (gloo) and leaves `value` null -- only the process plumbing is under test here."""
     import json
@@ -65,11 +68,11 @@ def test_bench_self_spawns_its_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
-                       capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup), "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["value"] is None
-    assert out["max_rank_seconds"] >= 0.02          # rank 1 sleeps longest: the line carries the MAX over ranks
+    assert out["dry_run"] is True and out["n_gpus"] == n and out["steps"] == steps and out["warmup"] == warmup and out["value"] is None
+    assert out["max_rank_seconds"] >= 0.01 * n      # the last rank sleeps longest: the line carries the MAX over ranks

@@ -620,3 +620,43 @@ def test_level1_boundary_callback_state_scheduler_pull_and_callback_loop(small64
     # descriptor loop, whose arithmetic produced them, whose source branch returns to z0)
     assert rel(out_native[0], xs[0, 0]) < 1.5e-2
     pipe.unet.set_controller(None)
+
+
+def test_sharded_sweep_under_torch_distributed_run(tmp_path):
+    """SURVEY 8e on real devices: `python -m torch.distributed.run --nproc-per-node W run_editing_p2p.py ...` with W = min(2, visible GPUs)
+    -- one process per GPU, RCCL broadcast of the weight arena from rank 0 (rank 1 never loads weights), the 2-image work list sharded
+    round-robin -- against the same sweep in one plain process.  On a 1-GPU box W = 1 still runs the launcher, the rendezvous on 127.0.0.1,
+    the IPC environment and the rank-0 path; the panels must match the single-process run byte for byte (same kernels, same inputs)."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world = min(2, torch.cuda.device_count())
+    data = tmp_path / "data"
+    (data / "annotation_images" / "0_random").mkdir(parents=True)
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    mapping = {}
+    for i in range(2):
+        rel_path = "0_random/%03d.png" % i
+        Image.fromarray(np.roll(img, 31 * i, axis=1)).save(str(data / "annotation_images" / rel_path))
+        mapping["%012d" % i] = {"image_path": rel_path, "original_prompt": "a [cat] sitting on a wooden chair",
+                                "editing_prompt": "a [dog] sitting on a wooden chair", "editing_type_id": "0", "blended_word": "cat dog",
+                                "mask": [0, 100]}
+    (data / "mapping_file.json").write_text(json.dumps(mapping))
+    common = [os.path.join(root, "run_editing_p2p.py"), "--data_path", str(data), "--model_config", "small64", "--synthetic_weights",
+              "--num_ddim_steps", "3", "--edit_category_list", "0", "--no_overlap_stages"]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)            # the driver must set it itself (distributed.prepare_env)
+    out_d, out_s = tmp_path / "out_dist", tmp_path / "out_single"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                        "--master-port", "29617"] + common + ["--output_path", str(out_d)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if world > 1:
+        assert "weight arena broadcast over RCCL" in r.stdout
+    r = subprocess.run([sys.executable] + common + ["--output_path", str(out_s)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for i in range(2):
+        a = np.array(Image.open(str(out_d / "directinversion+p2p" / "annotation_images" / "0_random" / ("%03d.png" % i))))
+        b = np.array(Image.open(str(out_s / "directinversion+p2p" / "annotation_images" / "0_random" / ("%03d.png" % i))))
+        assert a.shape == (512, 2048, 3) and np.array_equal(a, b), i

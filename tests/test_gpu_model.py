@@ -304,3 +304,52 @@ def test_pipeline_with_native_text_encoder():
                                       pipe.tokenizer(["a cat on a chair"], padding="max_length", max_length=77).input_ids)
     assert ((inv.context[2].cpu() - ref[0]).norm() / ref[0].norm()).item() < 4e-3
     pipe.engine.close()
+
+
+def test_attention_store_keep_maps_and_npi_slerp(tiny):
+    """Opt-in AttentionStore(keep_maps=True) (attention_control.py:214-248, what visualisation callers read): the <= 32^2-token
+    conditional-half maps of two UNet calls, summed, against the oracle's StoreController; and utils.slerp_tensor (negative-prompt
+    inversion's npi_interp, utils/utils.py:7-25) against its formula in float64."""
+    from oracle import p2p_oracle as po
+    from pnpinversion_amd.p2p import attention_control as ac
+    from pnpinversion_amd.pipeline import NativeUNet
+    from pnpinversion_amd.utils.utils import slerp_tensor
+    from types import SimpleNamespace
+    cfg, usd, vsd, eng = tiny
+    lat = _lat(cfg, 4, 61)
+    ctx = weights.synth_context(cfg, 4, seed=62)
+    unet = NativeUNet(eng)
+    store = ac.AttentionStore(keep_maps=True)
+    ac.register_attention_control(SimpleNamespace(unet=unet), store)
+    assert ac.is_callback_controller(unet.controller)
+    ref = po.StoreController(unet.num_att_layers)
+    for t in (800, 300):
+        got = unet(lat, t, encoder_hidden_states=ctx)["sample"]
+        with torch.no_grad():
+            want = sd_oracle.unet_forward(usd, cfg, lat, t, ctx, ref)
+        assert rel(got, want) < 4e-3
+    assert store.cur_step == 2 == ref.cur_step
+    avg = store.get_average_attention()
+    assert set(avg) == set(ref.attention_store)
+    n = 0
+    for key in avg:
+        assert len(avg[key]) == len(ref.attention_store[key]), key
+        for a, b in zip(avg[key], ref.attention_store[key]):
+            assert a.shape == b.shape and rel(a, b / 2) < 5e-3, (key, rel(a, b / 2))
+            n += 1
+    assert n == 32                                                        # TINY16: every site has <= 32^2 tokens
+    # the default AttentionStore stays the declarative no-op (flash kernels, nothing stored)
+    plain = ac.AttentionStore()
+    ac.register_attention_control(SimpleNamespace(unet=unet), plain)
+    assert not ac.is_callback_controller(unet.controller) and plain.tables() is None
+    unet(lat, 800, encoder_hidden_states=ctx)
+    assert plain.attention_store == {} and plain.cur_step == 1
+    ac.register_attention_control(SimpleNamespace(unet=unet), None)
+    # slerp
+    g = torch.Generator().manual_seed(5)
+    lo, hi = torch.randn(1, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g)
+    got = slerp_tensor(0.3, lo, hi)
+    l64, h64 = lo.double().flatten(1), hi.double().flatten(1)
+    om = torch.acos(((l64 / l64.norm(dim=1, keepdim=True)) * (h64 / h64.norm(dim=1, keepdim=True))).sum(1))
+    want = (torch.sin(0.7 * om) / torch.sin(om)).unsqueeze(1) * l64 + (torch.sin(0.3 * om) / torch.sin(om)).unsqueeze(1) * h64
+    assert rel(got, want.reshape(lo.shape)) < 1e-6

@@ -82,7 +82,7 @@ def test_controller_descriptor_semantics():
 def test_method_dispatch_matches_reference():
     """P2PEditor.__call__: every one of the reference's 39 method strings goes to the handler, with the method-specific arguments,
     that the reference's own __call__ (models/p2p_editor.py:28-135) uses (tests/golden/method_dispatch.json); anything else raises the
-    reference's NotImplementedError message.  (The null-latent handler exists and says what is missing.)"""
+    reference's NotImplementedError message.  All 39 have a native path."""
     import json
     import types
     from pnpinversion_amd.p2p_editor import P2PEditor
@@ -91,10 +91,8 @@ def test_method_dispatch_matches_reference():
     ed = P2PEditor(["x"], "cpu", num_ddim_steps=50, pipeline=fake)
     for n in [n for n in dir(P2PEditor) if n.startswith("edit_image")]:
         setattr(ed, n, (lambda n: (lambda *a, **k: (n, k)))(n))
-    unbuilt = set()     # every string reaches its handler (edit_image_null_latent_inversion itself raises: checked below)
+    unbuilt = set()     # every string reaches its handler
     assert len(gold) == 40
-    with pytest.raises(NotImplementedError, match="not built"):
-        P2PEditor.edit_image_null_latent_inversion(ed, "x", "a", "b")
     for m, want in gold.items():
         if m == "__unknown__":
             with pytest.raises(NotImplementedError) as ei:

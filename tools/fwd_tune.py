@@ -9,8 +9,8 @@ from pnpinversion_amd import weights
 from pnpinversion_amd.config import SD1
 from pnpinversion_amd.engine import NativeEngine
 rows_list = [int(a) for a in sys.argv[1:]] or [12, 1]
-NAME = {0: "128", 1: "64", 4: "320", 5: "256n", 6: "256x320", 7: "256x256", 8: "64k4", 9: "128k2", 10: "128k2b", 11: "64k2", 12: "64x320", 13: "128n2", 14: "128b64", 15: "256nb64"}
-SINGLE = [0, 1, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8]
+NAME = {0: "128", 1: "64", 3: "256m", 4: "320", 5: "256n", 6: "256x320", 7: "256x256", 8: "64k4", 9: "128k2", 10: "128k2b", 11: "64k2", 12: "64x320", 13: "128n2", 14: "128b64", 15: "256nb64"}
+SINGLE = [0, 1, 3, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8]
 SPLIT_CFGS = [0, 1, 4, 5, 11, 14]
 SPLITS = [2, 3, 4, 6, 8, 12]
 eng = NativeEngine(SD1, max_unet_rows=max(rows_list + [4]), max_vae_images=1)
@@ -26,6 +26,8 @@ for rows in rows_list:
     lat = torch.randn(rows, 4, 64, 64, device="cuda"); ctx = torch.randn(rows, 77, 768, device="cuda")
     eng.text_kv_precompute(ctx)
     combos = [(-1, 0)] + [(c, 0) for c in SINGLE] + [(c, s) for s in SPLITS for c in SPLIT_CFGS]
+    if os.environ.get("FWD_TUNE_CFGS"):        # quick look at a few configurations: FWD_TUNE_CFGS="3,14"
+        combos = [(-1, 0)] + [(int(c), 0) for c in os.environ["FWD_TUNE_CFGS"].split(",")]
     us = collections.defaultdict(lambda: collections.defaultdict(float))    # shape -> "name/sN" -> us per forward (sum of its launches)
     cnt = collections.defaultdict(int)
     total = {}

@@ -28,3 +28,9 @@ for rep in range(2):
           % (rep, steps, n_it, dt, dt / max(1, n_it) * 1e3, c["unet_sample_forwards"], c.get("unet_backward_rows", -1)))
 print("losses step 0:", ["%.5f" % l for l in losses[0]])
 print("free/total GB", [x / 2**30 for x in torch.cuda.mem_get_info()])
+if os.environ.get("PROFILE"):
+    os.environ["PNPI_PROFILE_DUMP"] = os.environ.get("DUMP", "gpurun_out/null_text_launches.csv")
+    eng.profile_begin()
+    eng.null_text_optimize(xs[-2:], ctx[:1], ctx[1:], sch.timesteps.numpy()[:1], 7.5, num_inner_steps=3, epsilon=1e-5)
+    cls = eng.profile_end()
+    print("classes over 1 step x 3 iterations (launches, ms):", {k: (v["launches"], round(v["total_ms"], 2)) for k, v in cls.items() if v["launches"]})
