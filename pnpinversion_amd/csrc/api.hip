@@ -434,21 +434,23 @@ static int op_conv(pnpi_ctx* c, const half_t* x1, int C1, const half_t* x2, int 
   return igemm_prof(c, p, 2.0 * p.M * (double)w.cout * w.k * w.k * w.cin, sr);
 }
 
+struct GemmBatch { int n = 1; long sa = 0, sw = 0, sout = 0, soutT = 0; };   // n problems: strides of a / w / out in elements, of vt->outT in bytes
 static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const half_t* w, int ldw, int N, const float* bias,
                    const half_t* res, int ldres, half_t* out, int ldo, float alpha = 1.f, const VtOut* vt = nullptr,
-                   double alg_flops = -1.0, int geglu = 0) {
+                   double alg_flops = -1.0, int geglu = 0, const GemmBatch* gb = nullptr) {
   GemmP p; gemm_defaults(p);
+  if (gb && gb->n > 1) { p.nbatch = gb->n; p.sx1 = gb->sa; p.sw = gb->sw; p.sout = gb->sout; p.soutT = gb->soutT; }
   p.x1 = a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
   p.w = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = res; p.ldres = ldres; p.alpha = alpha;
   p.out = out; p.ldo = ldo; p.geglu = geglu;
   if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
-  c->ctr.executed_gemm_flops += 2.0 * M * N * K;
+  c->ctr.executed_gemm_flops += 2.0 * M * N * K * p.nbatch;
   if (c->dry) return 0;
   if (taping(c) && out) {        // plain row-major outputs only: the recording forward uses no transposed / fused-GEGLU epilogue
     TapeOp o; o.kind = TK_GEMM; o.x1 = a; o.lda = lda; o.M = M; o.K = K; o.w = w; o.ldw = ldw; o.N = N; o.res = res; o.out = out; o.ldo = ldo; o.alpha = alpha;
     c->tape->ops.push_back(o);
   }
-  return igemm_prof(c, p, alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K);
+  return igemm_prof(c, p, alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K * p.nbatch);
 }
 
 // ResnetBlock2D.forward (my_diffusers/models/resnet.py:331-365); x2 = skip tensor concatenated on the channel axis
@@ -842,41 +844,65 @@ static size_t attn_bwd_scratch_bytes(int Nq, int Nk, int dh) {
 static int attn_bwd_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp,
                                  int v_off, const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B,
                                  half_t* dq, half_t* dk, half_t* dv, void* scratch, size_t scratch_bytes) {
-  if (!scratch || scratch_bytes < attn_bwd_scratch_bytes(Nq, Nk, dh)) return fail(c, PNPI_ENOMEM, "attention backward scratch too small");
+  const size_t per = attn_bwd_scratch_bytes(Nq, Nk, dh);
+  if (!scratch || scratch_bytes < per) return fail(c, PNPI_ENOMEM, "attention backward scratch too small");
   if ((dh & 7) || (ldq & 7) || (ldk & 7) || (ldvp & 7) || (ldo & 7)) return fail(c, PNPI_ESHAPE, "attention backward: extents must be multiples of 8");
   const int ldp = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
-  char* sp = (char*)scratch;
-  auto take = [&](size_t bytes) { char* r = sp; sp += align_up(bytes, 256); return r; };
-  float* S = (float*)take((size_t)Nq * Nk * 4);
-  float* dP = (float*)take((size_t)Nq * Nk * 4);
-  half_t* P16 = (half_t*)take((size_t)Nq * ldp * 2);
-  half_t* dS16 = (half_t*)take((size_t)Nq * ldp * 2);
-  half_t* PT = (half_t*)take((size_t)Nk * ldq8 * 2);
-  half_t* dST = (half_t*)take((size_t)Nk * ldq8 * 2);
-  half_t* Kt = (half_t*)take((size_t)dh * ldp * 2);
-  half_t* Qt = (half_t*)take((size_t)dh * ldq8 * 2);
-  half_t* dOt = (half_t*)take((size_t)dh * ldq8 * 2);
+  // The heads of a row are independent problems of one shape: every step below is ONE launch over a group of `nb` heads (as many as
+  // the scratch holds; all of them with the tape's own scratch) -- a batched GEMM (grid z = head) or a row-wise kernel over nb * Nq rows.
+  // Head by head the same work was 13 launches of a few microseconds each per head: 3 300 launches per reverse walk.
+  const int nb_max = (int)std::min<size_t>((size_t)heads, scratch_bytes / per);
+  const size_t szS = align_up((size_t)Nq * Nk * 4, 256), szP = align_up((size_t)Nq * ldp * 2, 256), szT = align_up((size_t)Nk * ldq8 * 2, 256),
+               szK = align_up((size_t)dh * ldp * 2, 256), szQ = align_up((size_t)dh * ldq8 * 2, 256);
   for (int b = 0; b < B; ++b)
-    for (int h = 0; h < heads; ++h) {
-      const half_t* qh = q + (size_t)b * Nq * ldq + q_off + h * Dp;
-      const half_t* kh = k + (size_t)b * Nk * ldk + k_off + h * Dp;
-      const half_t* vh = v + (size_t)b * Nk * ldvp + v_off + h * Dp;
-      const half_t* doh = d_o + (size_t)b * Nq * ldo + h * dh;
+    for (int h0 = 0; h0 < heads; h0 += nb_max) {
+      const int nb = std::min(nb_max, heads - h0);
+      char* sp = (char*)scratch;
+      auto take = [&](size_t bytes_each) { char* r = sp; sp += bytes_each * nb; return r; };     // [nb] consecutive per-head buffers
+      float* S = (float*)take(szS);
+      float* dP = (float*)take(szS);
+      half_t* P16 = (half_t*)take(szP);
+      half_t* dS16 = (half_t*)take(szP);
+      half_t* PT = (half_t*)take(szT);
+      half_t* dST = (half_t*)take(szT);
+      half_t* Kt = (half_t*)take(szK);
+      half_t* Qt = (half_t*)take(szQ);
+      half_t* dOt = (half_t*)take(szQ);
+      const long eS = (long)(szS / 4), eP = (long)(szP / 2), eT = (long)(szT / 2), eK = (long)(szK / 2), eQ = (long)(szQ / 2);   // per-head strides in elements
+      const half_t* qh = q + (size_t)b * Nq * ldq + q_off + h0 * Dp;
+      const half_t* kh = k + (size_t)b * Nk * ldk + k_off + h0 * Dp;
+      const half_t* vh = v + (size_t)b * Nk * ldvp + v_off + h0 * Dp;
+      const half_t* doh = d_o + (size_t)b * Nq * ldo + h0 * dh;
+      GemmBatch gb; gb.n = nb;
       VtOut vs; vs.outT = S; vs.col0 = 0; vs.ld = Nk; vs.f32 = 1; vs.rpb = Nk;            // S[q][key] = scale * sum_d k[key][d] q[q][d]
-      CK(op_gemm(c, kh, ldk, Nk, dh, qh, ldq, Nq, nullptr, nullptr, 0, nullptr, Nq, scale, &vs));
-      CK(launch_softmax_rows_f32(S, (size_t)Nq, Nk, c->st));
+      gb.sa = Dp; gb.sw = Dp; gb.sout = 0; gb.soutT = (long)szS;
+      CK(op_gemm(c, kh, ldk, Nk, dh, qh, ldq, Nq, nullptr, nullptr, 0, nullptr, Nq, scale, &vs, -1.0, 0, &gb));
       VtOut vp; vp.outT = dP; vp.col0 = 0; vp.ld = Nk; vp.f32 = 1; vp.rpb = Nk;          // dP[q][key] = sum_d v[key][d] dO[q][d]
-      CK(op_gemm(c, vh, ldvp, Nk, dh, doh, ldo, Nq, nullptr, nullptr, 0, nullptr, Nq, 1.f, &vp));
-      CK(launch_f32_rows_to_f16_padded(S, (size_t)Nq, Nk, ldp, P16, c->st));
-      CK(launch_softmax_bwd_rows(S, dP, (size_t)Nq, Nk, ldp, scale, dS16, c->st));
-      CK(launch_transpose_f16(P16, ldp, Nq, Nk, PT, ldq8, c->st));
-      CK(launch_transpose_f16(dS16, ldp, Nq, Nk, dST, ldq8, c->st));
-      CK(launch_transpose_f16(kh, ldk, Nk, dh, Kt, ldp, c->st));
-      CK(launch_transpose_f16(qh, ldq, Nq, dh, Qt, ldq8, c->st));
-      CK(launch_transpose_f16(doh, ldo, Nq, dh, dOt, ldq8, c->st));
-      CK(op_gemm(c, dS16, ldp, Nq, ldp, Kt, ldp, dh, nullptr, nullptr, 0, dq + (size_t)b * Nq * ldq + q_off + h * Dp, ldq));        // dQ = dS K
-      CK(op_gemm(c, dST, ldq8, Nk, ldq8, Qt, ldq8, dh, nullptr, nullptr, 0, dk + (size_t)b * Nk * ldk + k_off + h * Dp, ldk));      // dK = dS^T Q
-      CK(op_gemm(c, PT, ldq8, Nk, ldq8, dOt, ldq8, dh, nullptr, nullptr, 0, dv + (size_t)b * Nk * ldvp + v_off + h * Dp, ldvp));    // dV = P^T dO
+      gb.sa = Dp; gb.sw = dh;
+      CK(op_gemm(c, vh, ldvp, Nk, dh, doh, ldo, Nq, nullptr, nullptr, 0, nullptr, Nq, 1.f, &vp, -1.0, 0, &gb));
+      if (szS == (size_t)Nq * Nk * 4 && szP == (size_t)Nq * ldp * 2) {
+        // the per-head buffers are dense: the row-wise kernels take all nb * Nq rows at once
+        CK(launch_softmax_rows_f32(S, (size_t)nb * Nq, Nk, c->st));
+        CK(launch_f32_rows_to_f16_padded(S, (size_t)nb * Nq, Nk, ldp, P16, c->st));
+        CK(launch_softmax_bwd_rows(S, dP, (size_t)nb * Nq, Nk, ldp, scale, dS16, c->st));
+      } else {
+        for (int i = 0; i < nb; ++i) {
+          CK(launch_softmax_rows_f32(S + i * eS, (size_t)Nq, Nk, c->st));
+          CK(launch_f32_rows_to_f16_padded(S + i * eS, (size_t)Nq, Nk, ldp, P16 + i * eP, c->st));
+          CK(launch_softmax_bwd_rows(S + i * eS, dP + i * eS, (size_t)Nq, Nk, ldp, scale, dS16 + i * eP, c->st));
+        }
+      }
+      CK(launch_transpose_f16(P16, ldp, Nq, Nk, PT, ldq8, c->st, nb, eP, eT));
+      CK(launch_transpose_f16(dS16, ldp, Nq, Nk, dST, ldq8, c->st, nb, eP, eT));
+      CK(launch_transpose_f16(kh, ldk, Nk, dh, Kt, ldp, c->st, nb, Dp, eK));
+      CK(launch_transpose_f16(qh, ldq, Nq, dh, Qt, ldq8, c->st, nb, Dp, eQ));
+      CK(launch_transpose_f16(doh, ldo, Nq, dh, dOt, ldq8, c->st, nb, dh, eQ));
+      gb.soutT = 0; gb.sout = Dp;
+      gb.sa = eP; gb.sw = eK;
+      CK(op_gemm(c, dS16, ldp, Nq, ldp, Kt, ldp, dh, nullptr, nullptr, 0, dq + (size_t)b * Nq * ldq + q_off + h0 * Dp, ldq, 1.f, nullptr, -1.0, 0, &gb));     // dQ = dS K
+      gb.sa = eT; gb.sw = eQ;
+      CK(op_gemm(c, dST, ldq8, Nk, ldq8, Qt, ldq8, dh, nullptr, nullptr, 0, dk + (size_t)b * Nk * ldk + k_off + h0 * Dp, ldk, 1.f, nullptr, -1.0, 0, &gb));   // dK = dS^T Q
+      CK(op_gemm(c, PT, ldq8, Nk, ldq8, dOt, ldq8, dh, nullptr, nullptr, 0, dv + (size_t)b * Nk * ldvp + v_off + h0 * Dp, ldvp, 1.f, nullptr, -1.0, 0, &gb)); // dV = P^T dO
     }
   return 0;
 }
@@ -1030,7 +1056,7 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
           CK(launch_pad_heads_f16(dy, (size_t)o.B * o.Nq, o.heads, o.dh, o.Dp, dyp, c->st));
           dy = dyp; ldo_eff = o.heads * o.Dp;
         }
-        const size_t need = attn_bwd_scratch_bytes(o.Nq, o.Nk, dh_eff);
+        const size_t need = attn_bwd_scratch_bytes(o.Nq, o.Nk, dh_eff) * (size_t)o.heads;      // every head of a row in one set of launches
         if (need > T.attn_scratch_bytes) {
           if (T.attn_scratch) CKH(hipFree(T.attn_scratch));
           T.attn_scratch = nullptr; T.attn_scratch_bytes = 0;

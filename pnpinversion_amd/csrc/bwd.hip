@@ -375,10 +375,12 @@ int launch_repack_dgrad(const half_t* w, int N, int Npad, int taps, int Cin, hal
 }
 
 // dst[c][r] = src[r][c] for r < R, c < Cc; dst rows are ld_dst long and zero beyond R (GEMM operands need their k-extent padded to 8).
-// 32 x 32 tiles through LDS (+1 padding), 256 threads.
+// 32 x 32 tiles through LDS (+1 padding), 256 threads; blockIdx.z = matrix of a batch.
 __global__ void __launch_bounds__(256) transpose_f16_kernel(const half_t* __restrict__ src, int ld_src, int R, int Cc, half_t* __restrict__ dst,
-                                                            int ld_dst) {
+                                                            int ld_dst, long s_src, long s_dst) {
   __shared__ half_t tile[32][33];
+  src += (size_t)blockIdx.z * s_src;
+  dst += (size_t)blockIdx.z * s_dst;
   const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
 #pragma unroll
@@ -393,9 +395,9 @@ __global__ void __launch_bounds__(256) transpose_f16_kernel(const half_t* __rest
     if (c < Cc && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][ty + 8 * i];
   }
 }
-int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st) {
-  if (R <= 0 || Cc <= 0 || ld_dst < R) return -3;
-  transpose_f16_kernel<<<dim3((ld_dst + 31) / 32, (Cc + 31) / 32), 256, 0, st>>>(src, ld_src, R, Cc, dst, ld_dst);
+int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st, int nbatch, long s_src, long s_dst) {
+  if (R <= 0 || Cc <= 0 || ld_dst < R || nbatch < 1) return -3;
+  transpose_f16_kernel<<<dim3((ld_dst + 31) / 32, (Cc + 31) / 32, nbatch), 256, 0, st>>>(src, ld_src, R, Cc, dst, ld_dst, s_src, s_dst);
   return (int)hipGetLastError();
 }
 

@@ -19,8 +19,18 @@
 static constexpr int BK = 64;
 static constexpr int LDS_LD = BK + 8;  // halfs
 
+// problem z of a batched launch (GemmP::nbatch): the operand / output pointers of that problem
+__device__ __forceinline__ void gemm_batch_offsets(GemmP& p, int z) {
+  p.x1 += (size_t)z * p.sx1;
+  p.w += (size_t)z * p.sw;
+  if (p.out) p.out += (size_t)z * p.sout;
+  if (p.outT) p.outT = (char*)p.outT + (size_t)z * p.soutT;
+}
+
 template <int BM, int BN, bool FASTK>
-__global__ void __launch_bounds__(256) igemm_kernel(GemmP p) {
+__global__ void __launch_bounds__(256) igemm_kernel(GemmP p_in) {
+  GemmP p = p_in;
+  if (p.nbatch > 1) gemm_batch_offsets(p, (int)blockIdx.z);
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int AV = BM / 32, WV = BN / 32;  // 16-byte vectors per thread per k-chunk
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -351,6 +361,7 @@ void gemm_defaults(GemmP& p) {
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
   p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1;
   p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr; p.res_late = 0; p.bias_init = 0;
+  p.nbatch = 1; p.sx1 = 0; p.sw = 0; p.sout = 0; p.soutT = 0;
 }
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
@@ -510,6 +521,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (force_split > 1) {
     split = force_split;
   }
+  if (p.nbatch > 1) { split = 1; if (cfg >= 8 && cfg <= 11) cfg = (cfg == 8 || cfg == 11) ? 1 : 0; }   // no split-K / k-groups across problems
   if (cfg >= 8 && !dma_ok) cfg = (cfg == 8 || cfg == 11) ? 1 : 0;
   if (cfg >= 3 && !dma_ok) cfg = 0;                                 // 256x128 / 128x320 / 128x256 exist only as LDS-DMA kernels
   // whatever chose the split (cost model or a caller-forced value): the slabs must fit the workspace and each split needs work
@@ -539,7 +551,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   const int bn = bn_sel;
   if (stats_tile_rows) *stats_tile_rows = p.stats ? bm : 0;
   p.slab = ws;
-  dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, split);
+  if (p.nbatch > 1) {
+    if (split != 1 || p.bias || p.res || p.stats || p.geglu || p.x2) return -8;     // batched launches: plain products only
+  }
+  dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.nbatch > 1 ? p.nbatch : split);
   int r = 0;
   // Ring depth by occupancy: with at most one block per CU nothing else covers the HBM latency of the weight stream (cold in a
   // forward: 1.7 GB of weights pass through per UNet call), and the whole 160 KB of LDS is free -- so sparse launches take an

@@ -29,6 +29,10 @@ struct GemmP {
   int bias_init;  // set by launch_igemm: the LDS-DMA kernel starts its accumulators at the bias (alpha == 1, no split-K) and its epilogue adds none
   int res_late;   // set by launch_igemm: the LDS epilogue adds the residual in its store loop instead of staging it
   int gx, gy, gz, tile_order;   // set by the launcher: logical tile grid and XCD-aware traversal order (see igemm_dma_kernel)
+  // nbatch > 1: the launch holds nbatch independent problems of the same shape (grid z = problem index; no split-K): problem z reads
+  // x1 + z * sx1, w + z * sw and writes out + z * sout (elements) / outT + z * soutT (bytes).  The attention backward's per-head GEMMs.
+  int nbatch;
+  long sx1, sw, sout, soutT;
 };
 void gemm_defaults(GemmP& p);
 // ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.
@@ -152,4 +156,5 @@ int launch_null_text_loss(const float* eps_u, const float* eps_c, const float* x
                           float grad_scale, float* d_eps_u, float* loss, hipStream_t st);
 int launch_adam_step(float* p, float* m, float* v, const float* g, int n, int k, float lr, float inv_scale, hipStream_t st);
 int launch_pad_heads_f16(const half_t* src, size_t R, int heads, int dh, int Dp, half_t* dst, hipStream_t st);
-int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st);
+int launch_transpose_f16(const half_t* src, int ld_src, int R, int Cc, half_t* dst, int ld_dst, hipStream_t st, int nbatch = 1, long s_src = 0,
+                         long s_dst = 0);   // nbatch matrices, s_src / s_dst elements apart
