@@ -59,30 +59,52 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
   const half_t* kbase = p.k + (size_t)krow * p.Nk * p.ldk + p.k_off + head * DP;
   const half_t* vbase = p.vt + ((size_t)vrow * p.heads + head) * DP * (size_t)p.ldv;
 
-  for (int kv0 = 0; kv0 < p.Nk; kv0 += KV_TILE) {
-    __syncthreads();
-    for (int idx = tid; idx < KV_TILE * (DP / 8); idx += 256) {
-      int r = idx / (DP / 8), v = idx - r * (DP / 8);
-      int tok = kv0 + r;
-      half8 val = tok < p.Nk ? ldg_half8(kbase + (size_t)tok * p.ldk + v * 8) : zero_half8();
-      *reinterpret_cast<half8*>(sK + r * SK_LD + v * 8) = val;
+  // One K / V^T tile per thread in registers: the NEXT tile's global loads are issued right after this tile was published in LDS and
+  // fly under its MFMAs and softmax (the loop used to load, store, synchronise and only then compute: every 64-key tile paid a full
+  // global round trip -- 16 of them in a row at the 32 x 32 level, with at most a few blocks per CU to cover for each other).
+  constexpr int NKR = KV_TILE * (DP / 8) / 256, NVR = DP * (KV_TILE / 8) / 256;
+  static_assert(KV_TILE * (DP / 8) % 256 == 0 && DP * (KV_TILE / 8) % 256 == 0, "a tile is a whole number of 16-byte vectors per thread");
+  half8 rk[NKR], rv[NVR];
+  auto gload = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) {
+      const int idx = tid + i * 256, r = idx / (DP / 8), v = idx - r * (DP / 8);
+      const int tok = kv0 + r;
+      rk[i] = tok < p.Nk ? ldg_half8(kbase + (size_t)tok * p.ldk + v * 8) : zero_half8();
     }
-    for (int idx = tid; idx < DP * (KV_TILE / 8); idx += 256) {
-      int d = idx >> 3, v = idx & 7;
-      int tok0 = kv0 + v * 8;
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) {
+      const int idx = tid + i * 256, d = idx >> 3, v = idx & 7;
+      const int tok0 = kv0 + v * 8;
       const half_t* src = vbase + (size_t)d * p.ldv + tok0;
-      half8 val;
       if (tok0 + 8 <= p.Nk) {
-        val = ldg_half8(src);
+        rv[i] = ldg_half8(src);
       } else {
+        half8 val;
 #pragma unroll
         for (int j = 0; j < 8; ++j) val[j] = (tok0 + j < p.Nk) ? src[j] : (half_t)0.f;
+        rv[i] = val;
       }
+    }
+  };
+  gload(0);
+  for (int kv0 = 0; kv0 < p.Nk; kv0 += KV_TILE) {
+    __syncthreads();                    // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) {
+      const int idx = tid + i * 256, r = idx / (DP / 8), v = idx - r * (DP / 8);
+      *reinterpret_cast<half8*>(sK + r * SK_LD + v * 8) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) {
+      const int idx = tid + i * 256, d = idx >> 3, v = idx & 7;
+      const half8 val = rv[i];
       half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
       *reinterpret_cast<half4*>(sV + d * SV_LD + v * 8) = lo;
       *reinterpret_cast<half4*>(sV + d * SV_LD + v * 8 + 4) = hi;
     }
     __syncthreads();
+    if (kv0 + KV_TILE < p.Nk) gload(kv0 + KV_TILE);
 
     floatx16 s[2];
 #pragma unroll
