@@ -21,7 +21,10 @@
 static constexpr int KV_TILE = 64;
 static constexpr int SV_LD = KV_TILE + 4;  // halfs; 136-byte rows: conflict-free ds_read_b64 over 32 rows
 
-template <int DP>
+// PF: prefetch the next K / V^T tile into registers under the current tile's work (self-attention: many key tiles, few workgroups);
+// without it the tile is loaded and stored in one go (cross-attention: two tiles, thousands of workgroups -- the extra registers of the
+// prefetch would only cost occupancy there).
+template <int DP, bool PF>
 __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
   constexpr int KS = DP / 16;  // k-steps over the head dim for S
   constexpr int OT = DP / 32;  // 32-wide output tiles over the head dim
@@ -87,9 +90,10 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
       }
     }
   };
-  gload(0);
+  if (PF) gload(0);
   for (int kv0 = 0; kv0 < p.Nk; kv0 += KV_TILE) {
     __syncthreads();                    // every wave is done reading the previous tile
+    if (!PF) gload(kv0);
 #pragma unroll
     for (int i = 0; i < NKR; ++i) {
       const int idx = tid + i * 256, r = idx / (DP / 8), v = idx - r * (DP / 8);
@@ -104,7 +108,7 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
       *reinterpret_cast<half4*>(sV + d * SV_LD + v * 8 + 4) = hi;
     }
     __syncthreads();
-    if (kv0 + KV_TILE < p.Nk) gload(kv0 + KV_TILE);
+    if (PF && kv0 + KV_TILE < p.Nk) gload(kv0 + KV_TILE);
 
     floatx16 s[2];
 #pragma unroll
@@ -363,14 +367,17 @@ int launch_attn_flash(const AttnP& p, hipStream_t st) {
     attn_flash_dma64_kernel<<<grid, 256, 0, st>>>(p);
     return (int)hipGetLastError();
   }
+  const bool pf = p.Nk > 2 * KV_TILE;
+#define LAUNCH_FLASH(D) (pf ? attn_flash_kernel<D, true><<<grid, 256, 0, st>>>(p) : attn_flash_kernel<D, false><<<grid, 256, 0, st>>>(p))
   switch (p.Dp) {
-    case 32: attn_flash_kernel<32><<<grid, 256, 0, st>>>(p); break;
-    case 64: attn_flash_kernel<64><<<grid, 256, 0, st>>>(p); break;
-    case 96: attn_flash_kernel<96><<<grid, 256, 0, st>>>(p); break;
-    case 128: attn_flash_kernel<128><<<grid, 256, 0, st>>>(p); break;
-    case 160: attn_flash_kernel<160><<<grid, 256, 0, st>>>(p); break;
+    case 32: LAUNCH_FLASH(32); break;
+    case 64: LAUNCH_FLASH(64); break;
+    case 96: LAUNCH_FLASH(96); break;
+    case 128: LAUNCH_FLASH(128); break;
+    case 160: LAUNCH_FLASH(160); break;
     default: return -5;
   }
+#undef LAUNCH_FLASH
   return (int)hipGetLastError();
 }
 
@@ -402,31 +409,66 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
   const int qtok = blockIdx.x * 128 + wave * 32 + ql;
   const bool qok = qtok < p.Nq;
 
-  // ---- stage K, V^T (both rows), Mmat^T and the coefficient vectors
-  for (int which = 0; which < 2; ++which) {
-    const int row = rows2[which];
-    const half_t* kbase = p.k + (size_t)row * p.Nk * p.ldk + p.k_off + head * DP;
-    for (int idx = tid; idx < CE_KEYS * (DP / 8); idx += 256) {
-      int r = idx / (DP / 8), v = idx - r * (DP / 8);
-      half8 val = r < p.Nk ? ldg_half8(kbase + (size_t)r * p.ldk + v * 8) : zero_half8();
-      *reinterpret_cast<half8*>(sK + (which * CE_KEYS + r) * SK_LD + v * 8) = val;
-    }
-    const half_t* vbase = p.vt + ((size_t)row * p.heads + head) * DP * (size_t)p.ldv;
-    for (int idx = tid; idx < DP * (CE_KEYS / 4); idx += 256) {
-      int d = idx / (CE_KEYS / 4), v = idx - d * (CE_KEYS / 4);
-      half4 val;
+  // ---- stage K, V^T (both rows), Mmat^T and the coefficient vectors.  A site at the 16 x 16 / 8 x 8 level is 16 / 8 workgroups, so a
+  // workgroup's own latency is the launch's: every staging loop issues eight 16-byte loads per thread before the first store (the loops
+  // used to pair each load with its store -- and V^T went element by element: ~170 dependent round trips per thread at DP = 160), and the
+  // query fragments of both rows are requested before the barrier instead of after it.
+  half8 qf2[2][KS];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { int tok = v * 4 + j; val[j] = tok < p.Nk ? vbase[(size_t)d * p.ldv + tok] : (half_t)0.f; }
-      *reinterpret_cast<half4*>(sV + (which * DP + d) * CE_LD + v * 4) = val;
-    }
+  for (int which = 0; which < 2; ++which) {
+    const half_t* qp = p.q + ((size_t)rows2[which] * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf2[which][ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
   }
-  {
-    const half_t* mm = p.mmatT + (size_t)pair * CE_KEYS * CE_KEYS;
-    for (int idx = tid; idx < CE_KEYS * (CE_KEYS / 4); idx += 256) {
-      int j = idx / (CE_KEYS / 4), v = idx - j * (CE_KEYS / 4);
-      half4 val = *reinterpret_cast<const half4*>(mm + j * CE_KEYS + v * 4);
-      *reinterpret_cast<half4*>(sM + j * CE_LD + v * 4) = val;
+  auto staged8 = [&](int n, auto load, auto store) {
+    for (int base = tid; base < n; base += 256 * 8) {
+      half8 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = base + u * 256; r[u] = idx < n ? load(idx) : zero_half8(); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = base + u * 256; if (idx < n) store(idx, r[u]); }
     }
+  };
+  {
+    constexpr int KV8 = CE_KEYS * (DP / 8);                 // 16-byte vectors of one row's K block
+    staged8(2 * KV8,
+            [&](int idx) {
+              const int which = idx / KV8, i = idx - which * KV8, r = i / (DP / 8), v = i - r * (DP / 8);
+              const half_t* kbase = p.k + (size_t)rows2[which] * p.Nk * p.ldk + p.k_off + head * DP;
+              return r < p.Nk ? ldg_half8(kbase + (size_t)r * p.ldk + v * 8) : zero_half8();
+            },
+            [&](int idx, half8 val) {
+              const int which = idx / KV8, i = idx - which * KV8, r = i / (DP / 8), v = i - r * (DP / 8);
+              *reinterpret_cast<half8*>(sK + (which * CE_KEYS + r) * SK_LD + v * 8) = val;
+            });
+    constexpr int VV8 = DP * (CE_KEYS / 8);                 // V^T rows are ldv (a multiple of 8) halfs long: whole 16-byte vectors
+    staged8(2 * VV8,
+            [&](int idx) {
+              const int which = idx / VV8, i = idx - which * VV8, d = i / (CE_KEYS / 8), v = i - d * (CE_KEYS / 8);
+              const half_t* vbase = p.vt + ((size_t)rows2[which] * p.heads + head) * DP * (size_t)p.ldv;
+              half8 val = v * 8 < p.ldv ? ldg_half8(vbase + (size_t)d * p.ldv + v * 8) : zero_half8();
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (v * 8 + j >= p.Nk) val[j] = (half_t)0.f;      // keys past Nk (the row's pad columns) contribute nothing
+              return val;
+            },
+            [&](int idx, half8 val) {
+              const int which = idx / VV8, i = idx - which * VV8, d = i / (CE_KEYS / 8), v = i - d * (CE_KEYS / 8);
+              half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
+              half_t* dst = sV + (which * DP + d) * CE_LD + v * 8;        // rows are 200 bytes: 8-byte aligned
+              *reinterpret_cast<half4*>(dst) = lo;
+              *reinterpret_cast<half4*>(dst + 4) = hi;
+            });
+    const half_t* mm = p.mmatT + (size_t)pair * CE_KEYS * CE_KEYS;
+    staged8(CE_KEYS * (CE_KEYS / 8),
+            [&](int idx) { return ldg_half8(mm + (size_t)idx * 8); },
+            [&](int idx, half8 val) {
+              const int j = idx / (CE_KEYS / 8), v = idx - j * (CE_KEYS / 8);
+              half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
+              half_t* dst = sM + j * CE_LD + v * 8;
+              *reinterpret_cast<half4*>(dst) = lo;
+              *reinterpret_cast<half4*>(dst + 4) = hi;
+            });
     for (int idx = tid; idx < CE_KEYS; idx += 256) {
       sC[idx] = p.c1[pair * CE_KEYS + idx];
       sC[CE_KEYS + idx] = p.c2[pair * CE_KEYS + idx];
@@ -440,10 +482,7 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
   floatx16 P[2][3];  // normalised probabilities, [src/tgt][key tile]
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
-    half8 qf[KS];
-    const half_t* qp = p.q + ((size_t)rows2[which] * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
+    const half8* qf = qf2[which];
     float mx = -INFINITY;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
