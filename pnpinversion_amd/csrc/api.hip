@@ -355,6 +355,8 @@ struct Tape {
   float* d_ctx = nullptr;                             // [rows * ctx_len * cross_dim] fp32
   void* attn_scratch = nullptr; size_t attn_scratch_bytes = 0;
 };
+static int g_vt_perm = 1;            // tuning "attn_vt_perm": V^T of the 4096-token self-attention sites in the permuted key order (A/B)
+static int g_op_attention_vt_perm = 0;   // tuning "op_attention_vt_perm": pnpi_op_attention is handed a permuted V^T (kernel tests)
 static inline bool taping(pnpi_ctx* c) { return c->tape && c->tape->rec && !c->dry; }
 // a recording forward (or the dry run that sizes the arenas for one) keeps every activation and takes the plain-layout transformer block
 static inline bool keep_acts(pnpi_ctx* c) { return c->tape && c->tape->rec; }
@@ -388,7 +390,7 @@ static int op_gn(pnpi_ctx* c, const half_t* x1, const half_t* x2, int C1, int C2
   return 0;
 }
 
-struct VtOut { void* outT = nullptr; int col0 = 1 << 30; int ld = 0; int f32 = 0; int rpb = 1; };
+struct VtOut { void* outT = nullptr; int col0 = 1 << 30; int ld = 0; int f32 = 0; int rpb = 1; int perm16 = 0; };
 
 
 static int igemm_prof(pnpi_ctx* c, const GemmP& p, double alg_flops, StatsReq* sr = nullptr) {
@@ -443,7 +445,7 @@ static int op_gemm(pnpi_ctx* c, const half_t* a, int lda, int M, int K, const ha
   p.x1 = a; p.C1 = K; p.ldx1 = lda; p.B = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.ksize = 1;
   p.w = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = res; p.ldres = ldres; p.alpha = alpha;
   p.out = out; p.ldo = ldo; p.geglu = geglu;
-  if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; }
+  if (vt) { p.outT = vt->outT; p.vt_col0 = vt->col0; p.vt_ld = vt->ld; p.vt_f32 = vt->f32; p.rows_per_batch = vt->rpb; p.vt_perm16 = vt->perm16; }
   c->ctr.executed_gemm_flops += 2.0 * M * N * K * p.nbatch;
   if (c->dry) return 0;
   if (taping(c) && out) {        // plain row-major outputs only: the recording forward uses no transposed / fused-GEGLU epilogue
@@ -538,13 +540,16 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   // call-back path: P V runs over the padded key count, so the pad columns of V^T must be zeros -- cleared BEFORE the projection fills
   // the real columns (only the 2 x 2 level of the narrow test configurations has a token count that is not a multiple of 8)
   if (c->attn_cb && !c->dry && ldv != N) CKH(hipMemsetAsync(vt, 0, (size_t)B * hd * ldv * sizeof(half_t), c->st));
+  // the 4096-token sites run the 64-wide LDS-DMA kernel, which reads V^T in the permuted key order (one ds_read_b128 per P V fragment):
+  // the projection's epilogue writes it that way (not under a host callback: the materialised path reads plain V^T)
+  const int vperm = (g_vt_perm && !c->attn_cb && N % 16 == 0 && attn_flash_uses_dma64(t.Dp, N, 0)) ? 1 : 0;
   {
-    VtOut v; v.outT = vt; v.col0 = 2 * hd; v.ld = ldv; v.f32 = 0; v.rpb = N;
+    VtOut v; v.outT = vt; v.col0 = 2 * hd; v.ld = ldv; v.f32 = 0; v.rpb = N; v.perm16 = vperm;
     CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qk, 2 * hd, 1.f, &v, 2.0 * M * 3.0 * C * C));
   }
   half_t* ao = talloc(c, (size_t)M * C);
   {
-    AttnP a; a.q = qk; a.ldq = 2 * hd; a.q_off = 0; a.k = qk; a.ldk = 2 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv;
+    AttnP a; a.q = qk; a.ldq = 2 * hd; a.q_off = 0; a.k = qk; a.ldk = 2 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv; a.vt_perm = vperm;
     a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
     const bool masa = use_ctrl && cd.masa_any && cur_step >= cd.masa_start_step && block_index >= cd.masa_start_layer;
@@ -2230,6 +2235,8 @@ int pnpi_set_tuning(const char* key, int value) {
   if (!strcmp(key, "text_kv")) { g_text_kv = value; return 0; }
   if (!strcmp(key, "temb_cache")) { g_temb_cache = value; return 0; }
   if (!strcmp(key, "gn_inline_rows")) { norm_set_tuning_gn_inline_rows(value); return 0; }
+  if (!strcmp(key, "attn_vt_perm")) { g_vt_perm = value; return 0; }
+  if (!strcmp(key, "op_attention_vt_perm")) { g_op_attention_vt_perm = value; return 0; }
   return igemm_set_tuning(key, value) == 0 ? 0 : PNPI_EINVAL;
 }
 int pnpi_op_gemm(pnpi_ctx* c, const void* a, int lda, const void* w, int ldw, int M, int N, int K, float alpha, const float* bias,
@@ -2533,6 +2540,7 @@ int pnpi_op_attention(pnpi_ctx* c, const void* q, int ldq, int q_off, const void
   AttnP a; a.q = (const half_t*)q; a.ldq = ldq; a.q_off = q_off; a.k = (const half_t*)k; a.ldk = ldk; a.k_off = k_off;
   a.vt = (const half_t*)vt; a.ldv = ldv; a.o = (half_t*)o; a.ldo = ldo; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.Dp = Dp; a.dh = dh;
   a.scale = scale; a.rows = rows_dev; a.nrows = nrows;
+  a.vt_perm = (g_op_attention_vt_perm && attn_flash_uses_dma64(Dp, Nk, 0)) ? 1 : 0;
   CK(launch_attn_flash(a, c->st));
   return 0;
 }

@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+template <bool VPERM>
 __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   constexpr int DP = 64, KS = 4, OT = 2;
   constexpr int STAGE = 2 * 64 * 128;   // K tile + V^T tile, bytes
@@ -328,9 +329,15 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
         for (int t = 0; t < 2; ++t) {
           // keys st*32 + t*16 + 4h + [0,4) and + 8: 16-byte chunks 4*st + 2*t and + 1 of row d, sub-offset 8h bytes
           const int c0 = st * 4 + t * 2;
-          half4 lo = *reinterpret_cast<const half4*>(sV + ot * 4096 + ((c0 ^ x7) * 16) + 8 * h);
-          half4 hi = *reinterpret_cast<const half4*>(sV + ot * 4096 + (((c0 + 1) ^ x7) * 16) + 8 * h);
-          half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          half8 vf;
+          if (VPERM) {
+            // permuted key order (vt_perm16_pos): chunk c0 + h IS this lane's 8 keys, in accumulator-row order
+            vf = *reinterpret_cast<const half8*>(sV + ot * 4096 + (((c0 + h) ^ x7) * 16));
+          } else {
+            half4 lo = *reinterpret_cast<const half4*>(sV + ot * 4096 + ((c0 ^ x7) * 16) + 8 * h);
+            half4 hi = *reinterpret_cast<const half4*>(sV + ot * 4096 + (((c0 + 1) ^ x7) * 16) + 8 * h);
+            vf = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
           O[ot] = mfma32(vf, pf[st][t], O[ot]);
         }
     }
@@ -357,6 +364,12 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   }
 }
 
+// which launches the 64-wide LDS-DMA kernel takes (the producer of V^T may then write the permuted key order)
+bool attn_flash_uses_dma64(int Dp, int Nk, int causal) {
+  static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
+  return Dp == 64 && Nk % 64 == 0 && Nk >= 128 && !no_dma && !causal;
+}
+
 int launch_attn_flash(const AttnP& p, hipStream_t st) {
   if (p.nrows <= 0) return 0;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.q_off & 7) || (p.k_off & 7) || (p.dh & 3) || (p.ldo & 3)) return -3;
@@ -364,9 +377,11 @@ int launch_attn_flash(const AttnP& p, hipStream_t st) {
   dim3 grid((unsigned)(((total + 7) / 8) * 8), 1, 1);
   static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
   if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma && !p.causal) {
-    attn_flash_dma64_kernel<<<grid, 256, 0, st>>>(p);
+    if (p.vt_perm) attn_flash_dma64_kernel<true><<<grid, 256, 0, st>>>(p);
+    else attn_flash_dma64_kernel<false><<<grid, 256, 0, st>>>(p);
     return (int)hipGetLastError();
   }
+  if (p.vt_perm) return -6;        // only the kernel above reads the permuted layout
   const bool pf = p.Nk > 2 * KV_TILE;
 #define LAUNCH_FLASH(D) (pf ? attn_flash_kernel<D, true><<<grid, 256, 0, st>>>(p) : attn_flash_kernel<D, false><<<grid, 256, 0, st>>>(p))
   switch (p.Dp) {

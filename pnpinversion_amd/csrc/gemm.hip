@@ -359,7 +359,7 @@ void gemm_defaults(GemmP& p) {
   p.x1 = nullptr; p.x2 = nullptr; p.C1 = 0; p.C2 = 0; p.ldx1 = 0; p.ldx2 = 0;
   p.B = 1; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.ksize = 1; p.stride = 1; p.pad = 0; p.ups = 0;
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
-  p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1;
+  p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1; p.vt_perm16 = 0;
   p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr; p.res_late = 0; p.bias_init = 0;
   p.nbatch = 1; p.sx1 = 0; p.sw = 0; p.sout = 0; p.soutT = 0;
 }
@@ -545,6 +545,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (vt_lds) p.stats = nullptr;
   p.res_late = g_res_late;
   p.bias_init = (dma_ok && split == 1 && p.bias && p.alpha == 1.f && p.N % 4 == 0 && ((uintptr_t)p.bias & 15) == 0 && g_bias_init) ? 1 : 0;
+  if (p.vt_perm16 && (p.rows_per_batch % 16 != 0 || p.vt_f32)) return -9;   // permuted V^T: whole 16-token groups, fp16
   if (p.geglu && !(p.epi_lds && dma_ok && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
   const int bm = c256m ? 256 : (c64 ? 64 : 128);

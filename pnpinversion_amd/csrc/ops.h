@@ -22,6 +22,7 @@ struct GemmP {
   float alpha;
   half_t* out; int ldo;
   void* outT; int vt_col0, vt_ld, vt_f32, rows_per_batch;
+  int vt_perm16;   // transposed columns: token t of each aligned 16-token group is stored at position vt_perm16_pos(t) (see below)
   float* slab; int splitk, kchunks_per_split;
   float* stats;   // optional: per (m-tile, channel) sum / sum-of-squares of the fp16 output, [gridDim.x][N][2] (GroupNorm fusion)
   int geglu;      // N columns are [x(32) | gate(32)] interleaved groups; output has N/2 columns: x * gelu(gate)
@@ -87,6 +88,11 @@ int launch_f16_to_f32(const half_t* in, size_t n, float* out, hipStream_t st);
 // ---------------------------------------------------------------------------------------------------------------
 // Attention
 // ---------------------------------------------------------------------------------------------------------------
+// Key order of a "permuted" V^T (GemmP::vt_perm16 / AttnP::vt_perm): inside every aligned group of 16 tokens the two middle quads are
+// swapped -- stored order [0-3, 8-11, 4-7, 12-15] -- so that the 8 keys one lane feeds to the P V MFMA (accumulator rows 4h + {0..3, 8..11}
+// of a 16-key step) are ONE aligned 16-byte chunk: a single conflict-free ds_read_b128 instead of two 2-way-conflicted ds_read_b64.
+__host__ __device__ inline int vt_perm16_pos(int tok) { return tok ^ ((((tok >> 2) ^ (tok >> 3)) & 1) ? 12 : 0); }
+
 struct AttnP {
   const half_t* q; int ldq, q_off;
   const half_t* k; int ldk, k_off;
@@ -97,8 +103,10 @@ struct AttnP {
   const int* rows;                // device [nrows][4] = {out_row, q_row, k_row, v_row}
   int nrows;
   int causal = 0;                 // 1: key j is masked for query i when j > i (CLIP text encoder)
+  int vt_perm = 0;                // 1: vt is stored in the permuted key order (only the 64-wide LDS-DMA self-attention kernel reads it)
 };
 int launch_attn_flash(const AttnP& p, hipStream_t st);
+bool attn_flash_uses_dma64(int Dp, int Nk, int causal);
 
 // Cross-attention with the Prompt-to-Prompt edit fused in (one (src,tgt) row pair per grid.z entry).
 struct CrossEditP {

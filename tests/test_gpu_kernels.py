@@ -353,6 +353,35 @@ def test_attention_flash(ctx, B, heads, Nq, Nk, dh, Dp):
     assert rel_err(o, ref) < 3e-3, (rel_err(o, ref), max_err(o, ref))
 
 
+@pytest.mark.parametrize("B,heads,N", [(2, 2, 256), (1, 8, 4096)])
+def test_attention_flash_permuted_vt_and_its_producer(ctx, B, heads, N):
+    """The 4096-token sites: V^T in the permuted key order (each aligned 16-token group stored [0-3, 8-11, 4-7, 12-15], ops.h
+    vt_perm16_pos) read by the 64-wide LDS-DMA kernel with one 16-byte fragment load; and the producer -- a projection GEMM whose
+    transposed epilogue writes that order -- against a plain transpose."""
+    dh, Dp = 40, 64
+    q, k, v, qb, kb, vt, ldv = make_qkv(B, heads, N, N, dh, Dp, seed=25)
+    pos = torch.arange(N, device=DEV)
+    swap = (((pos >> 2) ^ (pos >> 3)) & 1).bool()
+    perm_pos = torch.where(swap, pos ^ 12, pos)                 # token t lives at position perm_pos[t]
+    vtp = torch.empty_like(vt)
+    vtp[..., perm_pos] = vt[..., pos]
+    scale = dh ** -0.5
+    o = torch.zeros(B, N, heads * dh, dtype=torch.half, device=DEV)
+    rows = torch.arange(B, dtype=torch.int32, device=DEV).repeat_interleave(4).reshape(B, 4).contiguous()
+    assert ctx.lib.pnpi_set_tuning(b"op_attention_vt_perm", 1) == 0
+    try:
+        ctx.call("pnpi_op_attention", ptr(qb), heads * Dp, 0, ptr(kb), heads * Dp, 0, ptr(vtp), ldv, ptr(o), heads * dh, heads, N, N, Dp, dh,
+                 scale, ptr(rows), B)
+    finally:
+        ctx.lib.pnpi_set_tuning(b"op_attention_vt_perm", 0)
+    ref = ((q.float() @ k.float().transpose(-1, -2) * scale).softmax(-1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, heads * dh)
+    assert rel_err(o, ref) < 3e-3, rel_err(o, ref)
+    o2 = torch.zeros_like(o)
+    ctx.call("pnpi_op_attention", ptr(qb), heads * Dp, 0, ptr(kb), heads * Dp, 0, ptr(vt), ldv, ptr(o2), heads * dh, heads, N, N, Dp, dh, scale,
+             ptr(rows), B)
+    assert torch.equal(o, o2)          # the same numbers in the same order: bit-identical to the plain layout
+
+
 def test_attention_row_indirection(ctx):
     # self-attention replacement: output row 3 uses q,k of row 2 and its own v (attention_control.py:258-263)
     B, heads, N, dh, Dp = 4, 2, 128, 40, 64
