@@ -96,6 +96,10 @@ typedef struct {
   int masa_start_step;             /* kind 2: steps >= start_step (4) ...                   masactrl.py:36,61 */
   int masa_start_layer;            /* ... and transformer blocks >= start_layer (10, execution order 0..15): the target rows'
                                       self-attention reads K and V of the source row of their CFG half (masactrl.py:63-69) */
+  const float* lb_sub_alpha_host;  /* LocalBlend substruct_words: [2][77] substruct_layers one-hot rows, or NULL (none).  The blend mask
+                                      becomes mask & ~mask_sub, mask_sub = the same maps weighted by these rows, NOT max-pooled, thresholded
+                                      at lb_threshold_sub                                    attention_control.py:97-106,114-116,134-143 */
+  float lb_threshold_sub;          /* th[1] = 0.3 */
 } pnpi_ctrl_desc;
 
 /* Reconstruction guidance of the proximal-guidance loop (models/p2p/proximal_guidance_forward.py:48-51,60-72 with
@@ -357,6 +361,10 @@ int pnpi_op_cross_edit(pnpi_ctx* ctx, const void* q, int ldq, int q_off, const v
                        const float* lb_alpha, float* lb_acc, int lb_slot0, int lb_nslots);
 int pnpi_op_local_blend(pnpi_ctx* ctx, const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th,
                         float* latents, int nimg);
+/* The same with LocalBlend substruct_words: lb_acc holds 4 planes per slot (blend src / tgt, substruct src / tgt); the mask is
+ * (blend maps pooled > th) & ~(substruct maps unpooled > th_sub)  (attention_control.py:97-118). */
+int pnpi_op_local_blend_sub(pnpi_ctx* ctx, const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float th_sub,
+                            float* latents, int nimg);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
                        negative-prompt-inversion+p2p, a vary-guidance, a not_full, a skip_step and the add-target ablation):
                        inversion latents / offsets where they differ from e2e_refine, reconstruction and edited latents
   e2e_masactrl.npz     run_editing_masactrl.py MasaCtrlEditor: directinversion+masactrl and ddim+masactrl stage outputs
+  e2e_substruct.npz    AttentionRefine + LocalBlend(substruct_words=...) built from the reference's classes by hand, 4 + 4 steps
   e2e_proximal.npz     P2PEditor("negative-prompt-inversion+proximal-guidance") with the sweep script's arguments (l0) and l1
   e2e_proximal_recon.npz  the same method with use_reconstruction_guidance=True (masked pred-x0 pull + dilated edit mask), 4 steps
   e2e_null_text.npz    P2PEditor("null-text-inversion+p2p"): inversion latents, the optimised per-step unconditional embeddings, the loss
@@ -177,6 +178,65 @@ def e2e(name, is_replace, blend, steps=2, cfg=SMALL64, seed=2, pair=None, keep_e
                         src=src, tgt=tgt, blend=np.array([w0, w1]), steps=np.int64(steps), is_replace=np.bool_(is_replace),
                         use_blend=np.bool_(blend), weight_seed=np.int64(seed))
     print("e2e", name, "%.1fs" % (time.time() - t0))
+
+
+def local_blend_substruct(steps=4, th=(0.3, 0.6)):
+    """LocalBlend(substruct_words=...) (attention_control.py:97-118,134-143): no shipped script passes substruct_words (make_controller has
+    no argument for them), so the controller is built by hand from the reference's classes -- AttentionRefine with
+    LocalBlend([src, tgt], (("cat",), ("dog",)), substruct_words=(("chair",), ("chair",)), th=th) -- and run through the reference's
+    DirectInversion.invert + direct_inversion_p2p_guidance_forward (models/p2p_editor.py:430-472), SMALL64, 4 + 4 steps.  th[1] is chosen so
+    that the substruct mask is neither empty nor full on the seeded weights (the fractions of every get_mask call are stored)."""
+    ref_shim.install()
+    t0 = time.time()
+    cfg, seed = SMALL64, 2
+    usd, vsd = weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    model = ed.ldm_stable
+    src, tgt, w0, w1 = PROMPT_PAIRS[0]
+    sub = "chair"
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    from models.p2p.inversion import DirectInversion
+    from models.p2p.p2p_guidance_forward import direct_inversion_p2p_guidance_forward
+    from models.p2p.attention_control import AttentionRefine, LocalBlend
+    from utils.utils import load_512
+    fracs = []
+    orig_get_mask = LocalBlend.get_mask
+
+    def get_mask_spy(self, maps, alpha, use_pool):
+        m = orig_get_mask(self, maps, alpha, use_pool)
+        fracs.append([float(use_pool), float(m[1].float().mean())])
+        return m
+
+    LocalBlend.get_mask = get_mask_spy
+    try:
+        with ref_shim.cuda_to_cpu(), torch.no_grad():
+            inv = DirectInversion(model=model, num_ddim_steps=steps)
+            _, _, x_stars, noise_loss = inv.invert(image_gt=load_512(img), prompt=[src, tgt], guidance_scale=7.5)
+            lb = LocalBlend([src, tgt], ((w0,), (w1,)), substruct_words=((sub,), (sub,)), th=th, tokenizer=model.tokenizer, device="cpu",
+                            num_ddim_steps=steps)
+            ctrl = AttentionRefine([src, tgt], steps, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, local_blend=lb,
+                                   tokenizer=model.tokenizer, device="cpu")
+            latents, _ = direct_inversion_p2p_guidance_forward(model=model, prompt=[src, tgt], controller=ctrl, noise_loss_list=noise_loss,
+                                                               latent=x_stars[-1], num_inference_steps=steps, guidance_scale=7.5,
+                                                               generator=None)
+            # the same edit without the substruct words: what the substruct mask changes
+            lb0 = LocalBlend([src, tgt], ((w0,), (w1,)), th=th, tokenizer=model.tokenizer, device="cpu", num_ddim_steps=steps)
+            ctrl0 = AttentionRefine([src, tgt], steps, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, local_blend=lb0,
+                                    tokenizer=model.tokenizer, device="cpu")
+            nfr = len(fracs)
+            latents0, _ = direct_inversion_p2p_guidance_forward(model=model, prompt=[src, tgt], controller=ctrl0, noise_loss_list=noise_loss,
+                                                                latent=x_stars[-1], num_inference_steps=steps, guidance_scale=7.5,
+                                                                generator=None)
+    finally:
+        LocalBlend.get_mask = orig_get_mask
+    np.savez_compressed(os.path.join(OUT, "e2e_substruct.npz"), x_stars=torch.stack(list(x_stars)).numpy(),
+                        noise_loss=torch.stack(list(noise_loss)).numpy(), context=inv.context.numpy().astype(np.float16),
+                        edited_latents=latents.numpy(), edited_latents_no_substruct=latents0.numpy(),
+                        mask_fractions=np.array(fracs[:nfr], np.float64), src=src, tgt=tgt, blend=np.array([w0, w1]), substruct=np.array([sub, sub]),
+                        th=np.array(th, np.float64), steps=np.int64(steps), weight_seed=np.int64(seed))
+    print("local_blend_substruct %.1fs; get_mask (use_pool, fraction of the target mask set):" % (time.time() - t0), fracs[:nfr],
+          "| rel diff to the edit without substruct words %.3e" % float((latents[1] - latents0[1]).norm() / latents0[1].norm()))
 
 
 VARIANT_METHODS = ["ddim+p2p", "negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5",
@@ -622,6 +682,8 @@ if __name__ == "__main__":
         # the benchmarked configuration AND the benchmarked schedule: full SD-1.x width, 50 + 50 steps (about 45-60 min of CPU;
         # not part of the default list)
         e2e("sd1_50", False, True, steps=50, cfg=SD1, seed=0, keep_every=10)
+    if "substruct" in which or not sys.argv[1:]:
+        local_blend_substruct()
     if "variants" in which:
         variants()
     if "masactrl" in which:

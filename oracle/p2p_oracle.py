@@ -101,7 +101,7 @@ class EditController(StoreController):
     """AttentionControlEdit.forward (:269-282) with AttentionReplace (:303-304), AttentionRefine (:319-323),
     AttentionReweight (:340-345) and LocalBlend (:97-121).  `tables` are the host tables of make_controller (:366-405):
       cross_alpha [steps+1, 77]; kind "replace" (mapper [77,77]) or "refine" (mapper [77] int64, alphas [77]) or "none";
-      equalizer [77] or None; self_range (lo, hi); lb = dict(alpha_layers [2,77], start, th) or None."""
+      equalizer [77] or None; self_range (lo, hi); lb = dict(alpha_layers [2,77], start, th[, sub_alpha_layers [2,77], th_sub]) or None."""
 
     def __init__(self, num_att_layers, tables, batch_size=2):
         super().__init__(num_att_layers)
@@ -139,18 +139,29 @@ class EditController(StoreController):
             attn = torch.cat([base[None], new], dim=0).reshape(self.batch_size * h, *attn.shape[1:])
         return attn
 
+    @staticmethod
+    def _lb_get_mask(maps, alpha, use_pool, th, size):
+        # LocalBlend.get_mask (:97-106)
+        m = (maps * alpha).sum(-1).mean(1)
+        if use_pool:
+            m = F.max_pool2d(m, (3, 3), (1, 1), padding=(1, 1))
+        m = F.interpolate(m, size=size)
+        m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
+        m = m.gt(th)
+        return m[:1] + m
+
     def local_blend_mask(self, x_t):
         lb = self.t["lb"]
         maps = self.attention_store["down_cross"][2:4] + self.attention_store["up_cross"][:3]
         al = lb["alpha_layers"].to(x_t.dtype).reshape(2, 1, 1, 1, 1, MAX_NUM_WORDS)
         maps = [m.reshape(2, -1, 1, 16, 16, MAX_NUM_WORDS) for m in maps]
         maps = torch.cat(maps, dim=1)
-        m = (maps * al).sum(-1).mean(1)
-        m = F.max_pool2d(m, (3, 3), (1, 1), padding=(1, 1))
-        m = F.interpolate(m, size=x_t.shape[2:])
-        m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
-        m = m.gt(lb["th"])
-        return m[:1] + m
+        mask = self._lb_get_mask(maps, al, True, lb["th"], x_t.shape[2:])
+        if lb.get("sub_alpha_layers") is not None:
+            # substruct_words (:114-116): mask * ~get_mask(maps, substruct_layers, use_pool=False), thresholded at th[1]
+            sub = lb["sub_alpha_layers"].to(x_t.dtype).reshape(2, 1, 1, 1, 1, MAX_NUM_WORDS)
+            mask = mask * ~self._lb_get_mask(maps, sub, False, lb.get("th_sub", 0.3), x_t.shape[2:])
+        return mask
 
     def step_callback(self, x_t):
         lb = self.t.get("lb")

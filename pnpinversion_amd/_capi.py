@@ -34,6 +34,7 @@ class CtrlDesc(C.Structure):
         ("lb_enabled", C.c_int), ("lb_start", C.c_int), ("lb_threshold", C.c_float),
         ("lb_alpha_host", C.POINTER(C.c_float)),
         ("masa_start_step", C.c_int), ("masa_start_layer", C.c_int),
+        ("lb_sub_alpha_host", C.POINTER(C.c_float)), ("lb_threshold_sub", C.c_float),
     ]
 
 
@@ -125,6 +126,7 @@ SYMBOLS = {
     "pnpi_op_cross_edit": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp,
                                 _vp, _vp, _vp, _i, _i]),
     "pnpi_op_local_blend": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i]),
+    "pnpi_op_local_blend_sub": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i]),
 }
 
 _lib = None

@@ -598,7 +598,7 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
       const bool lb = cd.lb_any && t.lb_slot0 >= 0 && N == c->unet.lb_tokens;
       e.lb_alpha = lb ? cd.lb_alpha : nullptr;
       e.lb_acc = lb ? cd.lb_acc : nullptr;
-      e.lb_slot0 = t.lb_slot0; e.lb_nslots = c->unet.lb_nslots; e.write_src = 0;
+      e.lb_slot0 = t.lb_slot0; e.lb_nslots = c->unet.lb_nslots; e.lb_planes = cd.lb_planes; e.write_src = 0;
       PROF(PNPI_KC_ATTN_EDIT, 4.0 * 2 * cd.npairs * t.heads * (double)N * T * t.dh, 0.0, launch_attn_cross_edit(e, c->st));
     }
   }
@@ -1325,7 +1325,12 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
   cd.self_lo = d0.self_replace_lo; cd.self_hi = d0.self_replace_hi; cd.self_max_tokens = d0.self_replace_max_tokens;
   const int P = cd.npairs;
   std::vector<half_t> mm((size_t)P * 96 * 96, (half_t)0.f);
-  std::vector<float> coef((size_t)cd.n_alpha_rows * 2 * P * 96, 0.f), lba((size_t)P * 2 * 96, 0.f);
+  // LocalBlend planes: {src, tgt} blend-word selectors, plus {src, tgt} substruct-word selectors when any controller of the batch has them
+  int planes = 2;
+  for (int pi = 0; pi < P; ++pi)
+    if (cds[edit_img[pi]].lb_enabled && cds[edit_img[pi]].lb_sub_alpha_host) planes = 4;
+  cd.lb_planes = planes;
+  std::vector<float> coef((size_t)cd.n_alpha_rows * 2 * P * 96, 0.f), lba((size_t)P * planes * 96, 0.f);
   for (int pi = 0; pi < P; ++pi) {
     const pnpi_ctrl_desc& d = cds[edit_img[pi]];
     if (d.n_alpha_rows != cd.n_alpha_rows || d.self_replace_lo != cd.self_lo || d.self_replace_hi != cd.self_hi ||
@@ -1344,12 +1349,17 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
     cd.lb_enabled.push_back(d.lb_enabled);
     cd.lb_start.push_back(d.lb_start);
     cd.lb_th.push_back(d.lb_threshold);
+    // a pair without substruct words in a 4-plane batch: its substruct maps are all zero and never exceed an infinite threshold
+    cd.lb_th_sub.push_back(d.lb_enabled && d.lb_sub_alpha_host ? d.lb_threshold_sub : INFINITY);
     if (d.lb_enabled) {
       if (!d.lb_alpha_host) return fail(c, PNPI_EINVAL, "lb_alpha missing");
       if (c->unet.lb_nslots == 0) return fail(c, PNPI_ESHAPE, "LocalBlend needs the five 16x16 cross-attention maps (latent 64x64 layout)");
       cd.lb_any = 1;
       for (int w = 0; w < 2; ++w)
-        for (int j = 0; j < T; ++j) lba[((size_t)pi * 2 + w) * 96 + j] = d.lb_alpha_host[w * T + j];
+        for (int j = 0; j < T; ++j) {
+          lba[((size_t)pi * planes + w) * 96 + j] = d.lb_alpha_host[w * T + j];
+          if (d.lb_sub_alpha_host) lba[((size_t)pi * planes + 2 + w) * 96 + j] = d.lb_sub_alpha_host[w * T + j];
+        }
     }
   }
   cd.mmatT = (half_t*)c->ctrl_arena.alloc(mm.size() * sizeof(half_t));
@@ -1359,7 +1369,7 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
   if (cd.lb_any) {
     cd.lb_alpha = misc_f(c, lba.size());
     CKP(upload(c, cd.lb_alpha, lba.data(), lba.size() * sizeof(float)));
-    size_t nacc = (size_t)P * c->unet.lb_nslots * 2 * c->unet.lb_tokens;
+    size_t nacc = (size_t)P * c->unet.lb_nslots * planes * c->unet.lb_tokens;
     cd.lb_acc = misc_f(c, nacc);
     CKH(hipMemsetAsync(cd.lb_acc, 0, nacc * sizeof(float), c->st));
   }
@@ -1376,9 +1386,9 @@ static int apply_local_blend(pnpi_ctx* c, float* latents /*[nimg][2][E]*/, int s
   for (int pi = 0; pi < cd.npairs; ++pi) {
     if (!cd.lb_enabled[pi]) continue;
     if (step_index + 1 <= cd.lb_start[pi]) continue;   // LocalBlend.counter > start_blend (attention_control.py:108-110)
-    const float* acc = cd.lb_acc + (size_t)pi * c->unet.lb_nslots * 2 * c->unet.lb_tokens;
+    const float* acc = cd.lb_acc + (size_t)pi * c->unet.lb_nslots * cd.lb_planes * c->unet.lb_tokens;
     CK(launch_local_blend(acc, c->unet.lb_nslots, mhw, g.sample_size, g.in_channels, cd.lb_th[pi],
-                          latents + (size_t)cd.pair_img[pi] * 2 * E, 1, c->st));
+                          latents + (size_t)cd.pair_img[pi] * 2 * E, 1, c->st, cd.lb_planes, cd.lb_th_sub[pi]));
   }
   return 0;
 }
@@ -1482,7 +1492,7 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
   {
     const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
     size_t cap = ((size_t)8 << 20) + (size_t)max_unet_rows * E * sizeof(float) * 8 +
-                 (size_t)max_unet_rows * (96 * 96 * 2 + 64 * 2 * 96 * 4 * 2 + (size_t)c->unet.lb_nslots * 2 * c->unet.lb_tokens * 4);
+                 (size_t)max_unet_rows * (96 * 96 * 2 + 64 * 2 * 96 * 4 * 2 + (size_t)c->unet.lb_nslots * 4 * c->unet.lb_tokens * 4);
     CKH(hipMalloc((void**)&c->ctrl_arena.base, cap));
     c->ctrl_arena.cap = cap;
   }
@@ -2557,6 +2567,11 @@ int pnpi_op_cross_edit(pnpi_ctx* c, const void* q, int ldq, int q_off, const voi
 }
 int pnpi_op_local_blend(pnpi_ctx* c, const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents, int nimg) {
   CK(launch_local_blend(lb_acc, nslots, map_hw, lat_hw, C, th, latents, nimg, c->st));
+  return 0;
+}
+int pnpi_op_local_blend_sub(pnpi_ctx* c, const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float th_sub,
+                            float* latents, int nimg) {
+  CK(launch_local_blend(lb_acc, nslots, map_hw, lat_hw, C, th, latents, nimg, c->st, 4, th_sub));
   return 0;
 }
 

@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
   half_t* sK = reinterpret_cast<half_t*>(smem_raw);   // [2][96][SK_LD]   (src, tgt)
   half_t* sV = sK + 2 * CE_KEYS * SK_LD;              // [2][DP][CE_LD]
   half_t* sM = sV + 2 * DP * CE_LD;                   // [96][CE_LD]      Mmat^T[j][w]
-  float* sC = reinterpret_cast<float*>(sM + CE_KEYS * CE_LD);  // c1[96], c2[96], lb_alpha[2][96]
+  float* sC = reinterpret_cast<float*>(sM + CE_KEYS * CE_LD);  // c1[96], c2[96], lb_alpha[4][96] (blend src / tgt, substruct src / tgt)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
@@ -487,8 +487,9 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
     for (int idx = tid; idx < CE_KEYS; idx += 256) {
       sC[idx] = p.c1[pair * CE_KEYS + idx];
       sC[CE_KEYS + idx] = p.c2[pair * CE_KEYS + idx];
-      sC[2 * CE_KEYS + idx] = p.lb_alpha ? p.lb_alpha[(pair * 2 + 0) * CE_KEYS + idx] : 0.f;
-      sC[3 * CE_KEYS + idx] = p.lb_alpha ? p.lb_alpha[(pair * 2 + 1) * CE_KEYS + idx] : 0.f;
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl)
+        sC[(2 + pl) * CE_KEYS + idx] = (p.lb_alpha && pl < p.lb_planes) ? p.lb_alpha[(pair * p.lb_planes + pl) * CE_KEYS + idx] : 0.f;
     }
   }
   __syncthreads();
@@ -569,18 +570,20 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
   // LocalBlend accumulators (deterministic: each (slot, branch, query) word has exactly one writer per launch)
   if (p.lb_acc) {
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
+    for (int pl = 0; pl < 4; ++pl) {
+      if (pl >= p.lb_planes) break;            // planes 2, 3: the substruct-word selectors on the same two probability maps
+      const int which = pl & 1;
       float acc = 0.f;
 #pragma unroll
       for (int st = 0; st < 3; ++st)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int j = st * 32 + acc_row(r, lane);
-          acc += sC[(2 + which) * CE_KEYS + j] * P[which][st][r];
+          acc += sC[(2 + pl) * CE_KEYS + j] * P[which][st][r];
         }
       acc += __shfl_xor(acc, 32, 64);
       if (h == 0 && qok) {
-        float* dst = p.lb_acc + (((size_t)pair * p.lb_nslots + p.lb_slot0 + head) * 2 + which) * p.Nq + qtok;
+        float* dst = p.lb_acc + (((size_t)pair * p.lb_nslots + p.lb_slot0 + head) * p.lb_planes + pl) * p.Nq + qtok;
         *dst += acc;
       }
     }
@@ -632,7 +635,7 @@ __global__ void __launch_bounds__(256) attn_cross_edit_kernel(CrossEditP p) {
 
 template <int DP>
 static size_t ce_lds_bytes() {
-  return (size_t)(2 * CE_KEYS * (DP + 8) + 2 * DP * CE_LD + CE_KEYS * CE_LD) * sizeof(half_t) + 4 * CE_KEYS * sizeof(float);
+  return (size_t)(2 * CE_KEYS * (DP + 8) + 2 * DP * CE_LD + CE_KEYS * CE_LD) * sizeof(half_t) + 6 * CE_KEYS * sizeof(float);
 }
 
 template <int DP>

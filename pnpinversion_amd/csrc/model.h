@@ -131,6 +131,8 @@ struct CtrlDev {
   int lb_any = 0;
   std::vector<int> lb_start;      // per pair
   std::vector<float> lb_th;
+  std::vector<float> lb_th_sub;   // per pair; +inf when the pair has no substruct words
+  int lb_planes = 2;              // 2, or 4 when any pair of the batch has substruct words
   std::vector<int> lb_enabled;
   std::vector<int> pair_img;      // pair -> image
   int self_lo = 0, self_hi = 0, self_max_tokens = 0;
@@ -145,8 +147,8 @@ struct CtrlDev {
   int* pairs = nullptr;           // [npairs][2]
   half_t* mmatT = nullptr;        // [npairs][96][96]
   float* coef = nullptr;          // [n_alpha_rows][2][npairs][96]  (c1 block, c2 block per step)
-  float* lb_alpha = nullptr;      // [npairs][2][96]
-  float* lb_acc = nullptr;        // [npairs][nslots][2][tokens]
+  float* lb_alpha = nullptr;      // [npairs][lb_planes][96]
+  float* lb_acc = nullptr;        // [npairs][nslots][lb_planes][tokens]
 };
 
 // Text K / V cache: the cross-attention keys / values depend only on the text context, which is constant over a denoising loop

@@ -120,8 +120,9 @@ struct CrossEditP {
   int npairs;
   const half_t* mmatT;            // device [npairs][96][96] fp16: mmatT[j][w] = Mmat[w][j] (zero padded)
   const float* c1; const float* c2;   // device [npairs][96] blend coefficients for the current step
-  const float* lb_alpha;          // device [npairs][2][96] LocalBlend token selectors (nullable)
-  float* lb_acc;                  // device [npairs][nslots][2][Nq] accumulators (nullable)
+  const float* lb_alpha;          // device [npairs][lb_planes][96] LocalBlend token selectors (nullable)
+  float* lb_acc;                  // device [npairs][nslots][lb_planes][Nq] accumulators (nullable)
+  int lb_planes = 2;              // 2: {src, tgt} blend-word selectors; 4: + {src, tgt} substruct-word selectors (LocalBlend substruct_words)
   int lb_slot0, lb_nslots;        // this layer's first slot (slot = lb_slot0 + head)
   int write_src;                  // also store the source row's output (tests); the executor leaves that to the flash kernel
 };
@@ -144,7 +145,7 @@ int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_pe
 int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_t row_elems, float q, float* thr_out, hipStream_t st);
 int launch_fill_f32(float* p, int n, float v, hipStream_t st);
 int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents,
-                       int nimg, hipStream_t st);
+                       int nimg, hipStream_t st, int planes = 2, float th_sub = 0.3f);   // planes 4: planes 2, 3 are the substruct maps (no pooling, th_sub)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Activation-gradient kernels of the null-text path (bwd.hip)

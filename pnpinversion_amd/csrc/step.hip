@@ -211,48 +211,56 @@ int launch_fill_f32(float* p, int n, float v, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-// One block per image. lb_acc: [nimg][nslots][2][map_hw*map_hw] accumulated (summed over steps) selector-weighted maps.
-// maps -> mean over slots -> 3x3 max-pool (stride 1, pad 1) -> nearest resize to lat_hw -> / max -> > th
-// mask_tgt = mask_src | mask_tgt ;  x_tgt = x_src + mask_tgt * (x_tgt - x_src)   (latents [nimg][2][C][lat_hw^2])
+// One block per image. lb_acc: [nimg][nslots][planes][map_hw*map_hw] accumulated (summed over steps) selector-weighted maps; planes 0, 1 =
+// the blend words of the source / target prompt, planes 2, 3 (planes == 4) = the substruct words.
+// blend maps   -> mean over slots -> 3x3 max-pool (stride 1, pad 1) -> nearest resize to lat_hw -> / max -> > th      (get_mask, use_pool)
+// substruct    -> mean over slots ->              (no pooling)      -> nearest resize          -> / max -> > th_sub  (attention_control.py:97-118)
+// mask_tgt = (mask_src | mask_tgt) & ~(sub_src | sub_tgt);  x_tgt = x_src + mask_tgt * (x_tgt - x_src)   (latents [nimg][2][C][lat_hw^2])
 __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restrict__ lb_acc, int nslots, int mhw, int lhw, int C,
-                                                          float th, float* __restrict__ latents) {
+                                                          float th, float* __restrict__ latents, int planes, float th_sub) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_map = reinterpret_cast<float*>(smem_raw);  // [2][mhw*mhw]
-  float* s_pool = s_map + 2 * mhw * mhw;              // [2][mhw*mhw]
-  float* s_red = s_pool + 2 * mhw * mhw;              // [2][256]
-  const int img = blockIdx.x, tid = threadIdx.x;
   const int MP = mhw * mhw;
-  for (int idx = tid; idx < 2 * MP; idx += blockDim.x) {
+  float* s_map = reinterpret_cast<float*>(smem_raw);  // [4][MP]   mean maps
+  float* s_pool = s_map + 4 * MP;                     // [4][MP]   pooled (planes 0, 1) / copied (planes 2, 3)
+  float* s_red = s_pool + 4 * MP;                     // [4][256]
+  const int img = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < planes * MP; idx += blockDim.x) {
     int which = idx / MP, pix = idx - which * MP;
     float s = 0.f;
-    for (int sl = 0; sl < nslots; ++sl) s += lb_acc[(((size_t)img * nslots + sl) * 2 + which) * MP + pix];
+    for (int sl = 0; sl < nslots; ++sl) s += lb_acc[(((size_t)img * nslots + sl) * planes + which) * MP + pix];
     s_map[idx] = s / (float)nslots;
   }
   __syncthreads();
-  float lmax[2] = {-INFINITY, -INFINITY};
-  for (int idx = tid; idx < 2 * MP; idx += blockDim.x) {
+  float lmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int idx = tid; idx < planes * MP; idx += blockDim.x) {
     int which = idx / MP, pix = idx - which * MP;
     int y = pix / mhw, x = pix - y * mhw;
     float m = -INFINITY;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        int yy = y + dy, xx = x + dx;
-        if (yy >= 0 && yy < mhw && xx >= 0 && xx < mhw) m = fmaxf(m, s_map[which * MP + yy * mhw + xx]);
-      }
+    if (which < 2) {
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < mhw && xx >= 0 && xx < mhw) m = fmaxf(m, s_map[which * MP + yy * mhw + xx]);
+        }
+    } else {
+      m = s_map[idx];
+    }
     s_pool[idx] = m;
-    lmax[which] = fmaxf(lmax[which], m);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (w == which) lmax[w] = fmaxf(lmax[w], m);
   }
-  s_red[tid] = lmax[0];
-  s_red[256 + tid] = lmax[1];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) s_red[w * 256 + tid] = lmax[w];
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (tid < off) {
-      s_red[tid] = fmaxf(s_red[tid], s_red[tid + off]);
-      s_red[256 + tid] = fmaxf(s_red[256 + tid], s_red[256 + tid + off]);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s_red[w * 256 + tid] = fmaxf(s_red[w * 256 + tid], s_red[w * 256 + tid + off]);
     }
     __syncthreads();
   }
-  const float mx0 = s_red[0], mx1 = s_red[256];
+  const float mx0 = s_red[0], mx1 = s_red[256], mx2 = s_red[512], mx3 = s_red[768];
   const int LP = lhw * lhw;
   float* xs = latents + (size_t)img * 2 * C * LP;
   float* xt = xs + (size_t)C * LP;
@@ -265,6 +273,11 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
     float v0 = __fdiv_rn(s_pool[sy * mhw + sx], mx0);
     float v1 = __fdiv_rn(s_pool[MP + sy * mhw + sx], mx1);
     bool m = (v0 > th) || (v1 > th);
+    if (planes == 4) {
+      float u0 = __fdiv_rn(s_pool[2 * MP + sy * mhw + sx], mx2);
+      float u1 = __fdiv_rn(s_pool[3 * MP + sy * mhw + sx], mx3);
+      m = m && !((u0 > th_sub) || (u1 > th_sub));
+    }
     float mf = m ? 1.f : 0.f;
     for (int c = 0; c < C; ++c) {
       float a = xs[(size_t)c * LP + pix], b = xt[(size_t)c * LP + pix];
@@ -274,8 +287,9 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
 }
 
 int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, int C, float th, float* latents, int nimg,
-                       hipStream_t st) {
-  size_t lds = (size_t)(4 * map_hw * map_hw + 512) * sizeof(float);
-  local_blend_kernel<<<nimg, 256, lds, st>>>(lb_acc, nslots, map_hw, lat_hw, C, th, latents);
+                       hipStream_t st, int planes, float th_sub) {
+  if (planes != 2 && planes != 4) return -3;
+  size_t lds = (size_t)(8 * map_hw * map_hw + 1024) * sizeof(float);
+  local_blend_kernel<<<nimg, 256, lds, st>>>(lb_acc, nslots, map_hw, lat_hw, C, th, latents, planes, th_sub);
   return (int)hipGetLastError();
 }

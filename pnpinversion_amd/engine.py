@@ -17,7 +17,7 @@ class ControllerTables:
     """Host tables of one image's Prompt-to-Prompt controller -> pnpi_ctrl_desc (see include/pnpi.h)."""
 
     def __init__(self, cross_alpha, mapper, alphas, equalizer, self_range, lb_alpha=None, lb_start=0, lb_threshold=0.3,
-                 self_max_tokens=32 ** 2):
+                 self_max_tokens=32 ** 2, lb_sub_alpha=None, lb_threshold_sub=0.3):
         f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
         self.cross_alpha = f(cross_alpha)      # [steps+1, 77]
         self.mapper = f(mapper)                # [77, 77]
@@ -28,6 +28,10 @@ class ControllerTables:
         self.lb_start = int(lb_start)
         self.lb_threshold = float(lb_threshold)
         self.self_max_tokens = int(self_max_tokens)
+        self.lb_sub_alpha = f(lb_sub_alpha) if lb_sub_alpha is not None else None   # [2, 77] LocalBlend substruct_layers
+        self.lb_threshold_sub = float(lb_threshold_sub)
+        if self.lb_sub_alpha is not None and self.lb_alpha is None:
+            raise ValueError("lb_sub_alpha (LocalBlend substruct_words) without lb_alpha (LocalBlend words)")
 
     def desc(self):
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
@@ -44,6 +48,8 @@ class ControllerTables:
         d.lb_start = self.lb_start
         d.lb_threshold = self.lb_threshold
         d.lb_alpha_host = fp(self.lb_alpha) if self.lb_alpha is not None else None
+        d.lb_sub_alpha_host = fp(self.lb_sub_alpha) if self.lb_sub_alpha is not None else None
+        d.lb_threshold_sub = self.lb_threshold_sub
         return d
 
 

@@ -38,14 +38,28 @@ def get_equalizer(text, word_select, values, tokenizer=None):
     return equalizer
 
 
+def _native_local_blend(lb, x_t, engine):
+    """LocalBlend.__call__ (attention_control.py:108-121) for a step loop that drives model.unet(...) itself (SURVEY 8b level 1):
+    `lb` carries the reference's attributes (counter, start_blend); the maps are the ones the cross-attention kernel accumulated over
+    the UNet calls of this edit (kept in the library between calls), the blend is the local_blend kernel."""
+    if engine is None:
+        raise RuntimeError("LocalBlend: the controller is not registered with a native UNet (register_attention_control(model, "
+                           "controller) first) -- the 16 x 16 maps it blends with live in the library, not in attention_store")
+    lb.counter += 1
+    if lb.counter > lb.start_blend:
+        x_t = engine.local_blend(x_t, lb.counter - 1)
+    return x_t
+
+
 class LocalBlend:
     """Holds the LocalBlend parameters (attention_control.py:123-147); the blend itself runs in the local_blend HIP kernel
     on the maps accumulated by the cross-attention kernel."""
 
+    def __call__(self, x_t, engine):
+        return _native_local_blend(self, x_t, engine)
+
     def __init__(self, prompts, words, substruct_words=None, start_blend=0.2, th=(.3, .3), tokenizer=None, device="cuda",
                  num_ddim_steps=50):
-        if substruct_words is not None:
-            raise NotImplementedError("substruct_words is not used by any shipped script and is not implemented natively")
         alpha_layers = torch.zeros(len(prompts), 1, 1, 1, 1, MAX_NUM_WORDS)
         for i, (prompt, words_) in enumerate(zip(prompts, words)):
             if type(words_) is str:
@@ -55,6 +69,15 @@ class LocalBlend:
                 alpha_layers[i, :, :, :, :, ind] = 1
         self.alpha_layers = alpha_layers
         self.substruct_layers = None
+        if substruct_words is not None:                 # attention_control.py:134-143
+            substruct_layers = torch.zeros(len(prompts), 1, 1, 1, 1, MAX_NUM_WORDS)
+            for i, (prompt, words_) in enumerate(zip(prompts, substruct_words)):
+                if type(words_) is str:
+                    words_ = [words_]
+                for word in words_:
+                    ind = get_word_inds(prompt, word, tokenizer)
+                    substruct_layers[i, :, :, :, :, ind] = 1
+            self.substruct_layers = substruct_layers
         self.start_blend = int(start_blend * num_ddim_steps)
         self.counter = 0
         self.th = th
@@ -161,6 +184,12 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
         self.local_blend = local_blend
         self.num_steps = num_steps
 
+    def step_callback(self, x_t):
+        """attention_control.py:253-256.  Only per-forward (level-1) drivers call this; the device-resident loops blend inside."""
+        if self.local_blend is not None:
+            x_t = self.local_blend(x_t, self.__dict__.get("_pnpi_engine"))
+        return x_t
+
     # host tables ------------------------------------------------------------------------------------------------------
     def _mapper_alphas(self):
         raise NotImplementedError
@@ -175,7 +204,10 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
             cross_alpha=self.cross_replace_alpha.reshape(self.num_steps + 1, MAX_NUM_WORDS).numpy(),
             mapper=mapper, alphas=alphas, equalizer=self._equalizer(), self_range=self.num_self_replace,
             lb_alpha=lb.alpha_layers.reshape(2, MAX_NUM_WORDS).numpy() if lb is not None else None,
-            lb_start=lb.start_blend if lb is not None else 0, lb_threshold=lb.th[0] if lb is not None else 0.3)
+            lb_start=lb.start_blend if lb is not None else 0, lb_threshold=lb.th[0] if lb is not None else 0.3,
+            lb_sub_alpha=(lb.substruct_layers.reshape(2, MAX_NUM_WORDS).numpy()
+                          if lb is not None and lb.substruct_layers is not None else None),
+            lb_threshold_sub=lb.th[1] if lb is not None else 0.3)
 
 
 class AttentionReplace(AttentionControlEdit):
@@ -260,12 +292,18 @@ def is_callback_controller(controller):
 
 class ForeignControllerAdapter:
     """An instance of the REFERENCE's own controller classes (models/p2p/attention_control.py, unmodified) whose edit the kernels know:
-    AttentionReplace / AttentionRefine / AttentionReweight without LocalBlend.  Their attributes are the same tensors this module's
-    classes build (mapper, alphas, equalizer, cross_replace_alpha, num_self_replace), so the descriptor is read off the object.  Step
-    bookkeeping (cur_step, between_steps, step_callback) stays on the wrapped object, where the reference's loop code reads it."""
+    AttentionReplace / AttentionRefine / AttentionReweight, with or without LocalBlend.  Their attributes are the same tensors this module's
+    classes build (mapper, alphas, equalizer, cross_replace_alpha, num_self_replace, LocalBlend's alpha_layers / substruct_layers /
+    start_blend / th), so the descriptor is read off the object.  Step bookkeeping (cur_step, between_steps, LocalBlend.counter)
+    stays on the wrapped object, where the reference's loop code reads it."""
 
     def __init__(self, wrapped):
         self.__dict__["wrapped"] = wrapped
+        if getattr(wrapped, "local_blend", None) is not None:
+            # the reference's loop calls `controller.step_callback(latents)` on ITS object (p2p_guidance_forward.py:62,116), whose
+            # LocalBlend reads attention_store -- empty here, the kernels keep the five 16 x 16 maps in the library.  The instance
+            # gets a step_callback that runs the same blend natively (counter / start_blend stay on the reference's LocalBlend).
+            wrapped.step_callback = lambda x_t: _native_local_blend(wrapped.local_blend, x_t, wrapped.__dict__.get("_pnpi_engine"))
 
     def __getattr__(self, name):
         return getattr(self.wrapped, name)
@@ -300,8 +338,15 @@ def _tables_from_attributes(c):
     mapper, alphas = _mapper_alphas_from_attributes(c)
     eq = (c.equalizer.detach().float().cpu().reshape(-1).numpy() if type(c).__name__ == "AttentionReweight"
           else np.ones(MAX_NUM_WORDS, dtype=np.float32))
+    lb = getattr(c, "local_blend", None)
+    lbk = {}
+    if lb is not None:
+        rows = lambda t: t.detach().float().cpu().reshape(2, MAX_NUM_WORDS).numpy()
+        sub = getattr(lb, "substruct_layers", None)
+        lbk = dict(lb_alpha=rows(lb.alpha_layers), lb_start=int(lb.start_blend), lb_threshold=float(lb.th[0]),
+                   lb_sub_alpha=rows(sub) if sub is not None else None, lb_threshold_sub=float(lb.th[1]))
     return ControllerTables(cross_alpha=cra.reshape(steps + 1, MAX_NUM_WORDS).numpy(), mapper=mapper, alphas=alphas, equalizer=eq,
-                            self_range=tuple(int(x) for x in c.num_self_replace), lb_alpha=None, lb_start=0, lb_threshold=0.3)
+                            self_range=tuple(int(x) for x in c.num_self_replace), **lbk)
 
 
 def adapt_foreign_controller(controller):
@@ -310,8 +355,9 @@ def adapt_foreign_controller(controller):
         (AttentionStore's stored maps are then NOT populated: only visualisation reads them; keep them by passing the object through
         `force_callback(controller)`);
       * this module's own classes: unchanged (they carry `.tables()`);
-      * the reference's AttentionReplace / Refine / Reweight WITHOUT LocalBlend: the kernel descriptor read off their attributes;
-      * anything else callable (LocalBlend needs the stored 16 x 16 maps; user subclasses): the call-back path, exact and slow."""
+      * the reference's AttentionReplace / Refine / Reweight, with or without LocalBlend: the kernel descriptor read off their
+        attributes (with LocalBlend the instance's step_callback is pointed at the native blend, see ForeignControllerAdapter);
+      * anything else callable (user subclasses): the call-back path, exact and slow."""
     if controller is None or getattr(controller, "_pnpi_force_callback", False) or hasattr(controller, "tables"):
         return controller
     name = type(controller).__name__
@@ -319,10 +365,10 @@ def adapt_foreign_controller(controller):
         return None
     if name == "AttentionStore":
         return _NoEditAdapter(controller)
-    if name in ("AttentionReplace", "AttentionRefine", "AttentionReweight") and getattr(controller, "local_blend", None) is None:
+    if name in ("AttentionReplace", "AttentionRefine", "AttentionReweight"):
         try:
             _tables_from_attributes(controller)
-        except (LookupError, AttributeError, IndexError):
+        except (LookupError, AttributeError, IndexError, TypeError, ValueError, RuntimeError):
             return controller
         return ForeignControllerAdapter(controller)
     return controller

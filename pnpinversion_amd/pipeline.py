@@ -136,6 +136,12 @@ class NativeUNet:
     def set_controller(self, controller):
         from .p2p.attention_control import is_callback_controller
         self.controller = controller
+        if controller is not None and getattr(controller, "local_blend", None) is not None:
+            # per-forward (level-1) drivers call controller.step_callback(latents): LocalBlend then runs on this engine's accumulators
+            try:
+                controller._pnpi_engine = self.engine
+            except AttributeError:
+                pass
         if not is_callback_controller(controller) and getattr(self, "_cb_for", None) is not None:
             # a host callback left by an earlier callback controller must not outlive it: the loop entry points (level 2) and the next
             # descriptor forward would otherwise run the stale Python controller

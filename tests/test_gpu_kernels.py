@@ -506,6 +506,34 @@ def test_local_blend(ctx):
     assert torch.equal(d_lat.cpu()[0], ref)
 
 
+def test_local_blend_substruct_words(ctx):
+    """LocalBlend with substruct_words (attention_control.py:97-118): mask = get_mask(alpha_layers, pooled, th[0]) *
+    ~get_mask(substruct_layers, NOT pooled, th[1]); planes 0, 1 of the accumulator are the blend maps, planes 2, 3 the substruct maps."""
+    nslots, mhw, lhw, Cc = 6, 16, 64, 4
+    g = torch.Generator().manual_seed(5)
+    acc = torch.rand(1, nslots, 4, mhw * mhw, generator=g)
+    acc[:, :, 2:] *= torch.rand(1, 1, 2, mhw * mhw, generator=g) ** 3          # peaked substruct maps: a real fraction below th[1]
+    lat = torch.randn(1, 2, Cc, lhw, lhw, generator=g)
+    d_lat, accd = lat.clone().to(DEV), acc.to(DEV)
+    th, th_sub = 0.3, 0.45
+    ctx.call("pnpi_op_local_blend_sub", ptr(accd), nslots, mhw, lhw, Cc, th, th_sub, ptr(d_lat), 1)
+
+    def get_mask(maps, use_pool, t):
+        if use_pool:
+            maps = F.max_pool2d(maps, (3, 3), (1, 1), padding=(1, 1))
+        m = F.interpolate(maps, size=(lhw, lhw))
+        m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
+        m = m.gt(t)
+        return m[:1] + m
+    planes = acc[0].permute(1, 0, 2).reshape(4, nslots, 1, mhw, mhw).mean(1)
+    mask = get_mask(planes[:2], True, th)
+    sub = get_mask(planes[2:], False, th_sub)
+    assert 0.05 < sub.float().mean() < 0.95 and 0.05 < (mask * ~sub).float().mean() < 0.95
+    x_t = lat[0]
+    ref = x_t[:1] + (mask * ~sub).float() * (x_t - x_t[:1])
+    assert torch.equal(d_lat.cpu()[0], ref)
+
+
 @pytest.mark.parametrize("prox", ["l0", "l1"])
 def test_proximal_step_bit_exact(ctx, prox):
     """pnpi_prox_threshold = torch.quantile(|eps_c - eps_u|, q) (sort + linear interpolation) and the soft-threshold inside the

@@ -153,6 +153,63 @@ def test_p2p_editor_end_to_end_against_reference_golden(small64, name, lockstep)
         ed("no-such-method+p2p", img, "a", "b")
 
 
+def test_local_blend_substruct_words_against_reference_golden(small64):
+    """LocalBlend(substruct_words=...): the cross-attention kernel accumulates four selector planes (blend src / tgt, substruct src /
+    tgt), the blend kernel masks with (pooled blend maps > th[0]) & ~(unpooled substruct maps > th[1]) (attention_control.py:97-118);
+    against the edit the reference's own classes produced (tests/golden/e2e_substruct.npz; the substruct mask covers 0.23 .. 0.81 of
+    the latent and changes the edit by 0.9 rel-L2).  Mask decisions that flip at the threshold are counted, as for plain LocalBlend."""
+    g = np.load(os.path.join(GOLD, "e2e_substruct.npz"))
+    pipe, eng, steps = small64, small64.engine, int(g["steps"])
+    pipe.scheduler.set_timesteps(steps)
+    ts = pipe.scheduler.timesteps.numpy()
+    prompts = [str(g["src"]), str(g["tgt"])]
+    w0, w1 = [str(x) for x in g["blend"]]
+    s0, s1 = [str(x) for x in g["substruct"]]
+    th = tuple(float(x) for x in g["th"])
+
+    def ctrl(sub):
+        lb = ac.LocalBlend(prompts, ((w0,), (w1,)), substruct_words=((s0,), (s1,)) if sub else None, th=th, tokenizer=pipe.tokenizer,
+                           num_ddim_steps=steps)
+        return ac.AttentionRefine(prompts, steps, {"default_": 0.4}, 0.6, local_blend=lb, tokenizer=pipe.tokenizer)
+    ctx = torch.from_numpy(g["context"]).float()
+    x_stars = torch.from_numpy(g["x_stars"])
+    nl = eng.offset_calculate(x_stars, ctx[None], ts, 7.5)          # native offsets, as in the real pipeline (see the test above)
+    assert rel(nl[:, 0], torch.from_numpy(g["noise_loss"])) < 1.5e-2
+    got = eng.edit_loop(x_stars[-1], ctx[None], nl, [ctrl(True).tables()], ts, 7.5)[0].cpu()
+    r, frac = masked_rel(got[1], torch.from_numpy(g["edited_latents"])[1], tol_frac=0.02)
+    assert frac <= 0.02 and r < 2.5e-2, (r, frac)
+    # the substruct planes are what made the difference: the same controller without them matches the golden's other edit
+    got0 = eng.edit_loop(x_stars[-1], ctx[None], nl, [ctrl(False).tables()], ts, 7.5)[0].cpu()
+    r0, frac0 = masked_rel(got0[1], torch.from_numpy(g["edited_latents_no_substruct"])[1], tol_frac=0.02)
+    assert frac0 <= 0.02 and r0 < 2.5e-2, (r0, frac0)
+    assert rel(got[1], got0[1]) > 0.5
+    # a batch that mixes a controller with substruct words and one without (4-plane accumulators, infinite threshold for the second
+    # image's substruct maps): each image as in its own call.  The offsets come from the batched call too (the source row only
+    # returns to x*_0 -- which LocalBlend copies into the target outside the mask -- with offsets of the same row configuration)
+    nl_b = eng.offset_calculate(torch.cat((x_stars, x_stars), 1), torch.stack((ctx, ctx)), ts, 7.5)
+    both = eng.edit_loop(torch.cat((x_stars[-1], x_stars[-1])), torch.stack((ctx, ctx)), nl_b,
+                         [ctrl(True).tables(), ctrl(False).tables()], ts, 7.5).cpu()
+    for i, one in enumerate((got, got0)):
+        assert rel(both[i, 0], x_stars[0][0]) < 2e-2
+        r, frac = masked_rel(both[i, 1], one[1], tol_frac=0.02)
+        assert frac <= 0.02 and r < 2.5e-2, (i, r, frac)
+    assert rel(both[0, 1], got0[1]) > 0.5 and rel(both[1, 1], got[1]) > 0.5
+    # level 1 (SURVEY 8b): a per-forward step loop -- model.unet(...) per step, then controller.step_callback(latents), as the
+    # reference's loop code does (p2p_guidance_forward.py:103-116).  LocalBlend runs from step_callback on the maps the library keeps
+    # between the UNet calls of one edit: the same kernels as the device-resident loop
+    from pnpinversion_amd.p2p.p2p_guidance_forward import _level1_loop
+    c1 = ctrl(True)
+    ac.register_attention_control(pipe, c1)
+    try:
+        lat = torch.cat((x_stars[-1], x_stars[-1])).cuda()
+        out1 = _level1_loop(pipe, c1, lat, lambda i: ctx.cuda(), 7.5, [n for n in nl[:, 0]], 1).cpu()
+    finally:
+        pipe.unet.set_controller(None)
+    assert c1.cur_step == steps and c1.local_blend.counter == steps
+    r, frac = masked_rel(out1[1], got[1], tol_frac=0.002)
+    assert frac <= 0.002 and r < 2e-3, (r, frac)
+
+
 @pytest.mark.parametrize("name", ["refine", "replace"])
 def test_pruned_schedule_matches_faithful(small64, name):
     """SURVEY.md Note D: the pruned-equivalent schedule (3 rows per step: the source latent assigned from the inversion trajectory)

@@ -213,7 +213,8 @@ def test_the_references_own_register_attention_control_hooks_the_native_unet():
     """SURVEY 8b level 1 with the reference's UNMODIFIED code (build container only): models/p2p/attention_control.register_attention_control
     walks NativeUNet.named_children(), finds the 32 markers of class `CrossAttention` (:62-81), assigns their .forward -- and the native UNet
     ends up with the controller the closure carries: a kernel descriptor for the reference's own AttentionReplace / Refine / Reweight objects
-    (read off their attributes, bit-identical to this package's classes), the call-back path for LocalBlend, nothing for controller=None."""
+    (read off their attributes, bit-identical to this package's classes; with LocalBlend -- substruct words included -- the instance's
+    step_callback is pointed at the native blend), nothing for controller=None."""
     from oracle import ref_shim
     if not ref_shim.available():
         pytest.skip("reference tree not on this machine")
@@ -243,6 +244,9 @@ def test_the_references_own_register_attention_control_hooks_the_native_unet():
                                           controller=ref_refine)          # (the reference's Reweight takes no tokenizer, :347-355)
         ref_lb = ref_ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok,
                                         local_blend=ref_ac.LocalBlend(prompts, (("cat",), ("dog",)), tokenizer=tok, num_ddim_steps=50))
+        ref_lb_sub = ref_ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok,
+                                            local_blend=ref_ac.LocalBlend(prompts, (("cat",), ("dog",)), substruct_words=(("chair",), ("wooden",)),
+                                                                          th=(0.3, 0.45), tokenizer=tok, num_ddim_steps=50))
         ref_store = ref_ac.AttentionStore()
     mine_replace = ac.AttentionReplace(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok)
     mine_refine = ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok)
@@ -264,9 +268,42 @@ def test_the_references_own_register_attention_control_hooks_the_native_unet():
         assert ref_c.cur_step == 1
         ref_c.cur_step = 0
 
-    # LocalBlend reads the stored 16 x 16 maps: the reference's object runs through the call-back path, untouched
-    ref_ac.register_attention_control(model, ref_lb)
-    assert model.unet.controller is ref_lb and ac.is_callback_controller(model.unet.controller) and ref_lb.num_att_layers == 32
+    # LocalBlend: the descriptor carries its selectors, and the reference object's step_callback (which would read the never-filled
+    # attention_store) is pointed at the native blend on the engine's accumulators; counter / start_blend stay on the reference's object
+    class _BlendEngine(_FakeEngine):
+        calls = []
+
+        def local_blend(self, x_t, step_index):
+            self.calls.append(step_index)
+            return x_t
+    beng = _BlendEngine(SD1)
+    bmodel = types.SimpleNamespace(unet=NativeUNet(beng), tokenizer=tok, device="cpu")
+    for ref_c, sub, th in ((ref_lb, None, (0.3, 0.3)), (ref_lb_sub, (("chair",), ("wooden",)), (0.3, 0.45))):
+        mine = ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok,
+                                  local_blend=ac.LocalBlend(prompts, (("cat",), ("dog",)), substruct_words=sub, th=th, tokenizer=tok,
+                                                            num_ddim_steps=50))
+        ref_ac.register_attention_control(bmodel, ref_c)
+        got = bmodel.unet.controller
+        assert isinstance(got, ac.ForeignControllerAdapter) and got.wrapped is ref_c and not ac.is_callback_controller(got)
+        a, b = got.tables(), mine.tables()
+        for k in ("cross_alpha", "mapper", "alphas", "equalizer", "lb_alpha"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        assert (a.lb_start, a.lb_threshold, a.lb_threshold_sub) == (b.lb_start, b.lb_threshold, b.lb_threshold_sub) == (10, th[0], th[1])
+        assert (a.lb_sub_alpha is None) == (sub is None) and (sub is None or np.array_equal(a.lb_sub_alpha, b.lb_sub_alpha))
+        if sub is not None:
+            assert a.lb_sub_alpha.sum(1).tolist() == [1.0, 1.0] and not np.array_equal(a.lb_sub_alpha[0], a.lb_sub_alpha[1])
+        # the reference's loop calls ITS object's step_callback once per step: blend from the 11th call on (counter > start_blend = 10)
+        beng.calls.clear()
+        x = torch.zeros(2, 4, 8, 8)
+        for mine_too in (ref_c, mine):
+            if mine_too is mine:
+                bmodel.unet.set_controller(mine)
+            for _ in range(12):
+                x = mine_too.step_callback(x)
+        assert beng.calls == [10, 11, 10, 11] and ref_c.local_blend.counter == 12 and mine.local_blend.counter == 12
+    with pytest.raises(RuntimeError, match="not registered with a native UNet"):
+        ac.AttentionRefine(prompts, 50, cross_replace_steps={"default_": 0.4}, self_replace_steps=0.6, tokenizer=tok,
+                           local_blend=ac.LocalBlend(prompts, (("cat",), ("dog",)), tokenizer=tok, num_ddim_steps=50)).step_callback(x)
     # a plain AttentionStore: no edit (its step bookkeeping still runs on the reference's object)
     ref_ac.register_attention_control(model, ref_store)
     assert model.unet.controller.tables() is None and model.unet.controller.wrapped is ref_store
