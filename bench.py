@@ -366,6 +366,19 @@ def main():
                     roofline["traffic_source"] = "profiles/%s: %s" % (os.path.basename(pmc), src_json.get(
                         "source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of 12-row UNet forwards (tools/fwd_only.py), mean per launch of this kernel"))
                     break
+        # the rocprofv3 --kernel-trace --stats average of the same kernel under `bench.py --no-extras` (committed summary): the HIP-event
+        # bracket above also carries the packet-processing gap in front of the kernel, which differs between boxes of the pool
+        stats_csv = os.path.join(prof, "round3_bench_noextras_kernel_stats.csv")
+        if roofline is not None and os.path.exists(stats_csv):
+            import csv
+            want = "igemm_dma_kernelI" + "E".join("Li%s" % a for a in roofline["kernel"].split("<")[1].rstrip(">").split(",")) + "EE"
+            for row in csv.DictReader(open(stats_csv)):
+                if want in row["Name"]:
+                    us = float(row["AverageNs"]) / 1e3
+                    roofline["rocprof"] = {"avg_launch_us": us, "calls": int(row["Calls"]),
+                                           "achieved": roofline["alg_flop_per_launch"] / us / 1e6, "frac": roofline["alg_flop_per_launch"] / us / 1e6 / MFMA_PEAK_TFLOPS,
+                                           "source": "profiles/round3_bench_noextras_kernel_stats.csv (committed; not this run)"}
+                    break
         n_img = args.steps * world
         per_rank_flops = executed_flops(ctr)
         out = {
