@@ -356,6 +356,7 @@ struct Tape {
   void* attn_scratch = nullptr; size_t attn_scratch_bytes = 0;
 };
 static int g_vt_perm = 1;            // tuning "attn_vt_perm": V^T of the 4096-token self-attention sites in the permuted key order (A/B)
+static int g_attn_bwd_flash = 1;     // tuning "attn_bwd_flash": self-attention backward without the [N][N] matrices in memory (0: the materialised form everywhere)
 static int g_op_attention_vt_perm = 0;   // tuning "op_attention_vt_perm": pnpi_op_attention is handed a permuted V^T (kernel tests)
 static inline bool taping(pnpi_ctx* c) { return c->tape && c->tape->rec && !c->dry; }
 // a recording forward (or the dry run that sizes the arenas for one) keeps every activation and takes the plain-layout transformer block
@@ -911,6 +912,67 @@ static int attn_bwd_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_of
     }
   return 0;
 }
+// Self-attention backward in flash form (attn.hip: attn_bwd_flash_kernel): three transposes (K^T, Q^T, dO^T of every head), then one launch
+// each for dQ (which also leaves the per-query log-sum-exp and D), dK and dV.  Workspace per batch row: 3 * heads * dh * N halfs +
+// 2 * heads * N floats -- at the 64 x 64 level 8 MB against the 8.6 GB-per-8-heads of the score matrices.
+static size_t attn_bwd_flash_scratch_bytes(int heads, int Nq, int Nk, int dh) {
+  const size_t ldk8 = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
+  return (size_t)heads * (align_up((size_t)dh * ldk8 * 2, 256) + 2 * align_up((size_t)dh * ldq8 * 2, 256) + 2 * align_up((size_t)Nq * 4, 256));
+}
+static bool attn_bwd_flash_shape(int Nq, int Nk, int Dp, int dh) {
+  // cross-attention (77 keys) keeps the materialised form: its score matrices are small, and its 77 keys would put one workgroup per head
+  // in front of a 4096-query walk
+  return g_attn_bwd_flash && Nq == Nk && Nq >= 64 && Nq % 64 == 0 && (Dp == 32 || Dp == 64 || Dp == 96 || Dp == 160) && dh <= Dp && !(dh & 7);
+}
+static bool attn_bwd_flash_ok(int heads, int Nq, int Nk, int Dp, int dh, size_t scratch_bytes) {
+  return attn_bwd_flash_shape(Nq, Nk, Dp, dh) && scratch_bytes >= attn_bwd_flash_scratch_bytes(heads, Nq, Nk, dh);
+}
+static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp,
+                          int v_off, const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B,
+                          half_t* dq, half_t* dk, half_t* dv, void* scratch) {
+  if ((ldq & 7) || (ldk & 7) || (ldvp & 7) || (ldo & 7) || (q_off & 7) || (k_off & 7) || (v_off & 7))
+    return fail(c, PNPI_ESHAPE, "attention backward: extents must be multiples of 8");
+  const int ldk8 = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
+  const size_t szK = align_up((size_t)dh * ldk8 * 2, 256), szQ = align_up((size_t)dh * ldq8 * 2, 256), szF = align_up((size_t)Nq * 4, 256);
+  char* sp = (char*)scratch;
+  half_t* Kt = (half_t*)sp; sp += szK * heads;
+  half_t* Qt = (half_t*)sp; sp += szQ * heads;
+  half_t* dOt = (half_t*)sp; sp += szQ * heads;
+  float* lse = (float*)sp; sp += szF * heads;
+  float* dsum = (float*)sp;
+  if (szF != (size_t)Nq * 4) return fail(c, PNPI_ESHAPE, "attention backward: Nq * 4 must be a multiple of 256");   // [heads][Nq] dense (Nq >= 64, % 64 == 0 in every caller)
+  for (int b = 0; b < B; ++b) {
+    const half_t* qh = q + (size_t)b * Nq * ldq + q_off;
+    const half_t* kh = k + (size_t)b * Nk * ldk + k_off;
+    const half_t* vh = v + (size_t)b * Nk * ldvp + v_off;
+    const half_t* doh = d_o + (size_t)b * Nq * ldo;
+    CK(launch_transpose_f16(kh, ldk, Nk, dh, Kt, ldk8, c->st, heads, Dp, (long)(szK / 2)));
+    CK(launch_transpose_f16(qh, ldq, Nq, dh, Qt, ldq8, c->st, heads, Dp, (long)(szQ / 2)));
+    CK(launch_transpose_f16(doh, ldo, Nq, dh, dOt, ldq8, c->st, heads, dh, (long)(szQ / 2)));
+    const BwdMat mq{qh, Dp, ldq, dh}, mk{kh, Dp, ldk, dh}, mv{vh, Dp, ldvp, dh}, mdo{doh, dh, ldo, dh};
+    const BwdMat tk{Kt, (long)(szK / 2), ldk8, dh}, tq{Qt, (long)(szQ / 2), ldq8, dh}, tdo{dOt, (long)(szQ / 2), ldq8, dh};
+    AttnBwdP a{};
+    a.heads = heads; a.scale = scale; a.lse = lse; a.dsum = dsum; a.out_hs = Dp; a.out_w = dh;
+    a.b1 = mq; a.b2 = mdo; a.l1 = mk; a.l2 = mv; a.lt = tk; a.nb = Nq; a.nl = Nk;
+    a.out = dq + (size_t)b * Nq * ldq + q_off; a.out_ld = ldq;
+    CK(launch_attn_bwd_flash(a, 0, Dp, c->st));
+    a.b1 = mk; a.b2 = mv; a.l1 = mq; a.l2 = mdo; a.lt = tq; a.nb = Nk; a.nl = Nq;
+    a.out = dk + (size_t)b * Nk * ldk + k_off; a.out_ld = ldk;
+    CK(launch_attn_bwd_flash(a, 1, Dp, c->st));
+    a.lt = tdo;
+    a.out = dv + (size_t)b * Nk * ldvp + v_off; a.out_ld = ldvp;
+    CK(launch_attn_bwd_flash(a, 2, Dp, c->st));
+  }
+  return 0;
+}
+// dq / dk / dv of one attention site: the flash form for self-attention, the materialised form otherwise
+static int attn_bwd(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp, int v_off,
+                    const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, half_t* dq, half_t* dk, half_t* dv,
+                    void* scratch, size_t scratch_bytes) {
+  if (scratch && attn_bwd_flash_ok(heads, Nq, Nk, Dp, dh, scratch_bytes))
+    return attn_bwd_flash(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch);
+  return attn_bwd_materialized(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch, scratch_bytes);
+}
 // ---------------------------------------------------------------------------------------------------- tape backward
 static half_t* tape_galloc(pnpi_ctx* c, size_t n_halfs) {
   Tape& T = *c->tape;
@@ -1061,7 +1123,8 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
           CK(launch_pad_heads_f16(dy, (size_t)o.B * o.Nq, o.heads, o.dh, o.Dp, dyp, c->st));
           dy = dyp; ldo_eff = o.heads * o.Dp;
         }
-        const size_t need = attn_bwd_scratch_bytes(o.Nq, o.Nk, dh_eff) * (size_t)o.heads;      // every head of a row in one set of launches
+        const size_t need = attn_bwd_flash_shape(o.Nq, o.Nk, o.Dp, dh_eff) ? attn_bwd_flash_scratch_bytes(o.heads, o.Nq, o.Nk, dh_eff)
+                                                                           : attn_bwd_scratch_bytes(o.Nq, o.Nk, dh_eff) * (size_t)o.heads;      // every head of a row in one set of launches
         if (need > T.attn_scratch_bytes) {
           if (T.attn_scratch) CKH(hipFree(T.attn_scratch));
           T.attn_scratch = nullptr; T.attn_scratch_bytes = 0;
@@ -1085,8 +1148,8 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
         CKP(grad_of(o.k, (size_t)o.B * o.Nk * o.ldk, &gk));
         CKP(grad_of(o.v, (size_t)o.B * o.Nk * o.ldv, &gv));
         // (the projection outputs have exactly one consumer each -- this attention -- so the kernels may overwrite, not accumulate)
-        CKP(attn_bwd_materialized(c, o.q, o.ldq, o.q_off, o.k, o.ldk, o.k_off, o.v, o.ldv, o.v_off, dy, ldo_eff, o.heads, o.Nq, o.Nk, o.Dp, dh_eff,
-                                  o.scale, o.B, gq, gk, gv, T.attn_scratch, T.attn_scratch_bytes));
+        CKP(attn_bwd(c, o.q, o.ldq, o.q_off, o.k, o.ldk, o.k_off, o.v, o.ldv, o.v_off, dy, ldo_eff, o.heads, o.Nq, o.Nk, o.Dp, dh_eff,
+                     o.scale, o.B, gq, gk, gv, T.attn_scratch, T.attn_scratch_bytes));
         break;
       }
       default: break;
@@ -2247,6 +2310,7 @@ int pnpi_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gn_inline_rows")) { norm_set_tuning_gn_inline_rows(value); return 0; }
   if (!strcmp(key, "attn_vt_perm")) { g_vt_perm = value; return 0; }
   if (!strcmp(key, "op_attention_vt_perm")) { g_op_attention_vt_perm = value; return 0; }
+  if (!strcmp(key, "attn_bwd_flash")) { g_attn_bwd_flash = value; return 0; }
   return igemm_set_tuning(key, value) == 0 ? 0 : PNPI_EINVAL;
 }
 int pnpi_op_gemm(pnpi_ctx* c, const void* a, int lda, const void* w, int ldw, int M, int N, int K, float alpha, const float* bias,
@@ -2497,8 +2561,8 @@ int pnpi_op_attention_bwd(pnpi_ctx* c, const void* q, int ldq, int q_off, const 
                           const void* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, void* dq, void* dk, void* dv,
                           void* scratch, size_t scratch_bytes) {
   if (!c || !q || !k || !v || !d_o || !dq || !dk || !dv) return PNPI_EINVAL;
-  CKP(attn_bwd_materialized(c, (const half_t*)q, ldq, q_off, (const half_t*)k, ldk, k_off, (const half_t*)v, ldv, v_off, (const half_t*)d_o, ldo,
-                            heads, Nq, Nk, Dp, dh, scale, B, (half_t*)dq, (half_t*)dk, (half_t*)dv, scratch, scratch_bytes));
+  CKP(attn_bwd(c, (const half_t*)q, ldq, q_off, (const half_t*)k, ldk, k_off, (const half_t*)v, ldv, v_off, (const half_t*)d_o, ldo,
+               heads, Nq, Nk, Dp, dh, scale, B, (half_t*)dq, (half_t*)dk, (half_t*)dv, scratch, scratch_bytes));
   return 0;
 }
 size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh) { return attn_bwd_scratch_bytes(Nq, Nk, dh); }

@@ -661,3 +661,230 @@ int launch_attn_cross_edit(const CrossEditP& p, hipStream_t st) {
     default: return -5;
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Flash-style attention BACKWARD (null-text path: the gradient has to pass through every self-attention of the UNet).
+//   O = softmax(scale Q K^T) V;  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - D), D[q] = sum_k P dP;  dQ = scale dS K;  dK = scale dS^T Q
+// without S, P, dP, dS ever in memory (the materialised form wrote and re-read 537 MB of fp32 scores per 64 x 64 site).
+// One kernel, three modes.  A workgroup owns 128 "block" rows (4 waves x 32: the MFMA B operand, in registers) and walks the "loop"
+// rows in tiles of LT (the A operand, staged in LDS):   tile[loop][block] = L1 . B1^T   (and L2 . B2^T)
+//   DQ  block = queries (Q, dO), loop = keys (K, V).  Pass 1: lse2[q] = log2 sum_k 2^(c S) and D[q], online (running max), stored for
+//       the other two modes.  Pass 2: dS^T = P^T o (dP^T - D)  ->  dQ^T += K^T . dS^T
+//   DK  block = keys (K, V), loop = queries (Q, dO):  dS = P o (dP - D)  ->  dK^T += Q^T . dS
+//   DV  block = keys (K),    loop = queries (Q):                              dV^T += dO^T . P
+// As in the forward kernel the probability / dS tile goes from the accumulator registers straight into the next MFMA as its B operand
+// (the k-slot permutation is applied to the transposed loop-side operand: two 8-byte reads per fragment).  Every output element has one
+// writer and a fixed summation order: deterministic.  10 tile products per (query tile, key tile) pair against the 5 of the
+// materialised form -- the price of no atomics and no second workspace.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DP, int LT, int MODE>
+__global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
+  constexpr int KS = DP / 16, OT = DP / 32, NT = LT / 32;
+  constexpr int SK_LD = DP + 8, LT_LD = LT + 4;
+  __shared__ __attribute__((aligned(16))) half_t sL1[LT * SK_LD];
+  __shared__ __attribute__((aligned(16))) half_t sL2[MODE == 2 ? 8 : LT * SK_LD];
+  __shared__ __attribute__((aligned(16))) half_t sLT[DP * LT_LD];
+  __shared__ float sLse[LT], sD[LT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  const int nbt = (p.nb + 127) >> 7, T = nbt * p.heads, per = (T + 7) >> 3;
+  const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tix >= T) return;
+  const int bt = tix % nbt, head = tix / nbt;
+  const int brow = bt * 128 + wave * 32 + ql;
+  const bool bok = brow < p.nb;
+
+  half8 f1[KS], f2[KS];
+  {
+    const half_t* s1 = p.b1.p + (size_t)head * p.b1.hs + (size_t)(bok ? brow : 0) * p.b1.ld + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) f1[ks] = (bok && ks * 16 + h * 8 < p.b1.w) ? ldg_half8(s1 + ks * 16) : zero_half8();
+    if constexpr (MODE != 2) {
+      const half_t* s2 = p.b2.p + (size_t)head * p.b2.hs + (size_t)(bok ? brow : 0) * p.b2.ld + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) f2[ks] = (bok && ks * 16 + h * 8 < p.b2.w) ? ldg_half8(s2 + ks * 16) : zero_half8();
+    }
+  }
+  auto stage_rows = [&](const BwdMat& M, half_t* dst, int l0) {
+    constexpr int NV = LT * (DP / 8);
+    for (int idx = tid; idx < NV; idx += 256) {
+      const int r = idx / (DP / 8), v = idx - r * (DP / 8);
+      const int row = l0 + r;
+      const half8 val = (row < p.nl && v * 8 < M.w) ? ldg_half8(M.p + (size_t)head * M.hs + (size_t)row * M.ld + v * 8) : zero_half8();
+      *reinterpret_cast<half8*>(dst + r * SK_LD + v * 8) = val;
+    }
+  };
+  auto stage_t = [&](int l0) {
+    constexpr int NV = DP * (LT / 8);
+    for (int idx = tid; idx < NV; idx += 256) {
+      const int d = idx / (LT / 8), v = idx - d * (LT / 8);
+      const int r0 = l0 + v * 8;
+      half8 val = zero_half8();
+      if (d < p.lt.w) {
+        const half_t* src = p.lt.p + (size_t)head * p.lt.hs + (size_t)d * p.lt.ld + r0;
+        if (r0 + 8 <= p.nl) {
+          val = ldg_half8(src);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (r0 + j < p.nl) val[j] = src[j];
+        }
+      }
+      half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
+      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8) = lo;
+      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8 + 4) = hi;
+    }
+  };
+  floatx16 s[NT], dp[NT];
+  auto tiles = [&]() {
+#pragma unroll
+    for (int st = 0; st < NT; ++st) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        s[st] = mfma32(*reinterpret_cast<const half8*>(sL1 + (st * 32 + ql) * SK_LD + ks * 16 + h * 8), f1[ks], s[st]);
+      if constexpr (MODE != 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[st][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          dp[st] = mfma32(*reinterpret_cast<const half8*>(sL2 + (st * 32 + ql) * SK_LD + ks * 16 + h * 8), f2[ks], dp[st]);
+      }
+    }
+  };
+  const float c = p.scale * 1.44269504088896340736f;
+  float lse2 = 0.f, dq = 0.f;
+  if constexpr (MODE == 0) {
+    float mrun = -INFINITY, lrun = 0.f, drun = 0.f;
+    for (int l0 = 0; l0 < p.nl; l0 += LT) {
+      __syncthreads();
+      stage_rows(p.l1, sL1, l0);
+      stage_rows(p.l2, sL2, l0);
+      __syncthreads();
+      tiles();
+      if (l0 + LT > p.nl) {
+#pragma unroll
+        for (int st = 0; st < NT; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (l0 + st * 32 + acc_row(r, lane) >= p.nl) s[st][r] = -INFINITY;
+      }
+      float mloc = s[0][0];
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[st][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(mrun, mloc);          // finite: every tile starts inside the key range
+      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);   // first tile: 2^-inf = 0
+      const float mc = mnew * c;
+      float ps = 0.f, pd = 0.f;
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], c, -mc));
+          ps += pv;
+          pd = __builtin_fmaf(pv, dp[st][r], pd);
+        }
+      lrun = __builtin_fmaf(lrun, alpha, ps);
+      drun = __builtin_fmaf(drun, alpha, pd);
+      mrun = mnew;
+    }
+    const float ltot = lrun + __shfl_xor(lrun, 32, 64), dtot = drun + __shfl_xor(drun, 32, 64);
+    lse2 = mrun * c + __log2f(ltot);
+    dq = dtot / ltot;
+    if (h == 0 && bok) {
+      p.lse[(size_t)head * p.nb + brow] = lse2;
+      p.dsum[(size_t)head * p.nb + brow] = dq;
+    }
+  }
+
+  floatx16 acc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
+  for (int l0 = 0; l0 < p.nl; l0 += LT) {
+    __syncthreads();
+    stage_rows(p.l1, sL1, l0);
+    if constexpr (MODE != 2) stage_rows(p.l2, sL2, l0);
+    stage_t(l0);
+    if constexpr (MODE != 0) {
+      if (tid < LT) {
+        const int row = l0 + tid;
+        sLse[tid] = row < p.nl ? p.lse[(size_t)head * p.nl + row] : INFINITY;     // 2^(x - inf) = 0: rows past the end contribute nothing
+        sD[tid] = row < p.nl ? p.dsum[(size_t)head * p.nl + row] : 0.f;
+      }
+    }
+    __syncthreads();
+    tiles();
+    half8 pf[NT][2];
+#pragma unroll
+    for (int st = 0; st < NT; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = st * 32 + acc_row(r, lane);
+        float lz, dz;
+        if constexpr (MODE == 0) { lz = (l0 + lr < p.nl) ? lse2 : INFINITY; dz = dq; }
+        else { lz = sLse[lr]; dz = sD[lr]; }
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][r], c, -lz));
+        float val = pv;
+        if constexpr (MODE != 2) val = pv * (dp[st][r] - dz);
+        pf[st][r >> 3][r & 7] = (half_t)val;
+      }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int st = 0; st < NT; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half_t* vb = sLT + (ot * 32 + ql) * LT_LD + st * 32 + t * 16 + 4 * h;
+          const half4 lo = *reinterpret_cast<const half4*>(vb);
+          const half4 hi = *reinterpret_cast<const half4*>(vb + 8);
+          const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          acc[ot] = mfma32(vf, pf[st][t], acc[ot]);
+        }
+  }
+  if (bok) {
+    const float osc = MODE == 2 ? 1.f : p.scale;
+    half_t* op = p.out + (size_t)head * p.out_hs + (size_t)brow * p.out_ld;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = ot * 32 + 8 * g + 4 * h;
+        if (d + 3 < p.out_w) {
+          half4 o4 = {(half_t)(acc[ot][4 * g] * osc), (half_t)(acc[ot][4 * g + 1] * osc), (half_t)(acc[ot][4 * g + 2] * osc),
+                      (half_t)(acc[ot][4 * g + 3] * osc)};
+          *reinterpret_cast<half4*>(op + d) = o4;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (d + j < p.out_w) op[d + j] = (half_t)(acc[ot][4 * g + j] * osc);
+        }
+      }
+  }
+}
+
+template <int DP, int LT>
+static int launch_abf(const AttnBwdP& p, int mode, hipStream_t st) {
+  const int T = ((p.nb + 127) >> 7) * p.heads;
+  const dim3 grid((unsigned)(((T + 7) / 8) * 8));
+  if (mode == 0) attn_bwd_flash_kernel<DP, LT, 0><<<grid, 256, 0, st>>>(p);
+  else if (mode == 1) attn_bwd_flash_kernel<DP, LT, 1><<<grid, 256, 0, st>>>(p);
+  else attn_bwd_flash_kernel<DP, LT, 2><<<grid, 256, 0, st>>>(p);
+  return (int)hipGetLastError();
+}
+int launch_attn_bwd_flash(const AttnBwdP& p, int mode, int Dp, hipStream_t st) {
+  if (p.nb <= 0 || p.nl <= 0 || mode < 0 || mode > 2) return -3;
+  switch (Dp) {
+    case 32: return launch_abf<32, 64>(p, mode, st);
+    case 64: return launch_abf<64, 64>(p, mode, st);
+    case 96: return launch_abf<96, 64>(p, mode, st);
+    case 160: return launch_abf<160, 32>(p, mode, st);
+    default: return -1;
+  }
+}

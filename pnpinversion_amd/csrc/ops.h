@@ -108,6 +108,20 @@ struct AttnP {
 int launch_attn_flash(const AttnP& p, hipStream_t st);
 bool attn_flash_uses_dma64(int Dp, int Nk, int causal);
 
+// Flash-style attention backward (null-text path): dQ / dK / dV of softmax(scale Q K^T) V without the [N][N] matrices in memory.
+struct BwdMat { const half_t* p; long hs; int ld; int w; };   // (head, row, col) -> p[head * hs + row * ld + col]; columns >= w read as zero (w % 8 == 0)
+struct AttnBwdP {
+  BwdMat b1, b2;                  // the workgroup's own ("block") rows, held in registers: DQ: Q, dO;  DK: K, V;  DV: K
+  BwdMat l1, l2;                  // the rows it walks ("loop" side, staged in LDS):        DQ: K, V;   DK: Q, dO; DV: Q
+  BwdMat lt;                      // loop side TRANSPOSED, (head, d, row) -> p[head * hs + d * ld + row], rows d >= w read as zero: DQ: K^T; DK: Q^T; DV: dO^T
+  int nb, nl, heads;              // block rows, loop rows
+  float scale;
+  float* lse;                     // [heads][queries] log2-domain log-sum-exp: written by DQ, read by DK / DV
+  float* dsum;                    // [heads][queries] sum_k P dP                   (same)
+  half_t* out; long out_hs; int out_ld, out_w;   // out[head * out_hs + block_row * out_ld + d], d < out_w
+};
+int launch_attn_bwd_flash(const AttnBwdP& p, int mode /*0 DQ, 1 DK, 2 DV*/, int Dp, hipStream_t st);   // -1: head width not instantiated
+
 // Cross-attention with the Prompt-to-Prompt edit fused in (one (src,tgt) row pair per grid.z entry).
 struct CrossEditP {
   const half_t* q; int ldq, q_off;

@@ -186,6 +186,49 @@ def test_attention_bwd_materialised(ctx, B, heads, Nq, Nk, dh, Dp):
         assert rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref) < 6e-3, rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref)
 
 
+@pytest.mark.parametrize("B,heads,Nq,dh,Dp", [(1, 8, 1024, 40, 64), (2, 4, 1024, 80, 96), (1, 4, 256, 160, 160), (1, 2, 4096, 40, 64),
+                                              (1, 2, 64, 8, 32), (2, 3, 192, 40, 64)])
+def test_attention_bwd_flash(ctx, B, heads, Nq, dh, Dp):
+    """Self-attention backward in flash form (no [N][N] matrices in memory: attn_bwd_flash_kernel, three modes) against autograd and
+    against the materialised form (tuning attn_bwd_flash = 0) on the same inputs; 192 = one and a half 128-row workgroups."""
+    g = torch.Generator(device="cpu").manual_seed(23)
+    scale = 1.0 / math.sqrt(dh)
+
+    def padded(n, amp=1.0):
+        t = torch.zeros(B, n, heads, Dp)
+        t[..., :dh] = torch.randn(B, n, heads, dh, generator=g) * amp
+        return t.reshape(B * n, heads * Dp).half().to(DEV)
+
+    q, k, v = padded(Nq, 1.5), padded(Nq, 1.5), padded(Nq)               # amp 1.5: peaked rows as well as flat ones
+    d_o = torch.randn(B * Nq, heads * dh, generator=g).half().to(DEV)
+    qr, kr, vr = [t.float().reshape(B, -1, heads, Dp)[..., :dh].permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v)]
+    o = torch.softmax(scale * qr @ kr.transpose(-1, -2), -1) @ vr
+    o.backward(d_o.float().reshape(B, Nq, heads, dh).permute(0, 2, 1, 3))
+    nbytes = ctx.lib.pnpi_op_attention_bwd_scratch_bytes(Nq, Nq, dh) * heads
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    got = {}
+    try:
+        for flash in (1, 0):
+            assert ctx.lib.pnpi_set_tuning(b"attn_bwd_flash", flash) == 0
+            dq, dk, dv = [torch.zeros_like(t) for t in (q, k, v)]
+            ctx.call("pnpi_op_attention_bwd", ptr(q), heads * Dp, 0, ptr(k), heads * Dp, 0, ptr(v), heads * Dp, 0, ptr(d_o), heads * dh, heads, Nq, Nq, Dp,
+                     dh, scale, B, ptr(dq), ptr(dk), ptr(dv), ptr(scratch), nbytes)
+            torch.cuda.synchronize()
+            got[flash] = (dq, dk, dv)
+    finally:
+        ctx.lib.pnpi_set_tuning(b"attn_bwd_flash", 1)
+    for name, i, ref in (("dq", 0, qr.grad), ("dk", 1, kr.grad), ("dv", 2, vr.grad)):
+        for flash in (1, 0):
+            gh = got[flash][i].float().reshape(B, Nq, heads, Dp)
+            assert (gh[..., dh:] == 0).all(), (name, flash)                                # pad columns untouched
+            e = rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref)
+            assert e < 6e-3, (name, flash, e)
+        # the two forms are different programs: they may not be bit-identical, but they differ by fp16 rounding only
+        a, b = got[1][i].float(), got[0][i].float()
+        assert not torch.equal(a, torch.zeros_like(a))
+        assert rel_err(a, b) < 4e-3, (name, rel_err(a, b))
+
+
 # ------------------------------------------------------------------------------------------------ whole-UNet context gradient, null-text loop
 def test_unet_context_gradient_against_oracle_autograd():
     """pnpi_unet_context_grad (recording forward + reverse walk over the ops) vs torch.autograd through the CPU oracle's UNet, TINY16."""

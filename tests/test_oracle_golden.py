@@ -294,7 +294,7 @@ def test_reconstruction_guidance_matches_reference():
     g = {"src": v["src"], "tgt": v["tgt"], "blend": v["blend"], "use_blend": True, "is_replace": False}
     recon = {"ref_image": torch.from_numpy(v["image_enc_latent"]), "recon_lr": float(v["recon_lr"]), "recon_t": int(v["recon_t"]),
              "dilate_mask": int(v["dilate_mask"])}
-    for prox in ("l0", "l1"):
+    for prox in (("l0", "l1") if SLOW else ("l0",)):      # l1 differs in the soft-threshold line only, pinned without the pull by the test above
         ctrl = po.EditController(32, _tables_from_product(g, steps))
         out = po.guidance_forward(unet_fn, x_stars[-1], c4, None, ctrl, ts, ac_, ac_[0], 7.5, prox=prox, quantile=0.75, recon=recon)
         # the edit mask / LocalBlend mask are hard decisions: an element within fp32 rounding of a threshold may fall on the other
