@@ -973,6 +973,18 @@ static int attn_bwd(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half
     return attn_bwd_flash(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch);
   return attn_bwd_materialized(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch, scratch_bytes);
 }
+static int gn_bwd_workspace(pnpi_ctx* c, int B, int HW, int G, float** out) {
+  const size_t need = groupnorm_bwd2_scratch_floats(B, HW, G);
+  if (need > c->gn_bwd_ws_floats) {
+    CKH(hipStreamSynchronize(c->st));                      // a launch in flight may still read the old buffer
+    if (c->gn_bwd_ws) CKH(hipFree(c->gn_bwd_ws));
+    c->gn_bwd_ws = nullptr; c->gn_bwd_ws_floats = 0;
+    CKH(hipMalloc((void**)&c->gn_bwd_ws, need * sizeof(float)));
+    c->gn_bwd_ws_floats = need;
+  }
+  *out = c->gn_bwd_ws;
+  return 0;
+}
 // ---------------------------------------------------------------------------------------------------- tape backward
 static half_t* tape_galloc(pnpi_ctx* c, size_t n_halfs) {
   Tape& T = *c->tape;
@@ -1090,6 +1102,28 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
       }
       case TK_GN: {
         const int C = o.C1 + o.C2;
+        if (!(C & 7) && !(o.C1 & 7) && o.G <= 64 && !(o.C2 && o.x2 == o.x1)) {
+          // three chip-wide phases, dx written (or added) straight into the gradient buffers of the concat sources
+          const size_t R = (size_t)o.B * o.HW;
+          auto dest = [&](const half_t* key, int Cw, GnbOut& out) -> int {
+            if (key == T.no_grad_input) { out = GnbOut{nullptr, 0, 0}; return 0; }
+            auto it = T.grads.find(key);
+            if (it == T.grads.end()) {
+              half_t* p = tape_galloc(c, R * Cw);
+              if (!p) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
+              T.grads[key] = p;
+              out = GnbOut{p, Cw, 0};
+            } else out = GnbOut{it->second, Cw, 1};
+            return 0;
+          };
+          GnbOut o1{nullptr, 0, 0}, o2{nullptr, 0, 0};
+          CKP(dest(o.x1, o.C1, o1));
+          if (o.C2) CKP(dest(o.x2, o.C2, o2));
+          float* ws = nullptr;
+          CKP(gn_bwd_workspace(c, o.B, o.HW, o.G, &ws));
+          CK(launch_groupnorm_bwd2(o.x1, o.x2, o.C1, o.C2, o.B, o.HW, o.G, o.eps, o.nw->g, o.nw->b, o.silu, dy, o1, o2, ws, c->st));
+          break;
+        }
         half_t* dx = tape_galloc(c, (size_t)o.B * o.HW * C);
         if (!dx) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
         CK(launch_groupnorm_bwd(o.x1, o.x2, o.C1, o.C2, o.B, o.HW, o.G, o.eps, o.nw->g, o.nw->b, o.silu, dy, dx, c->st));
@@ -1613,7 +1647,7 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
 void pnpi_destroy(pnpi_ctx* c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->st);
-  void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial,
+  void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial, c->gn_bwd_ws,
                   c->temb_table, c->temb_h, c->temb_emb, c->bias_scratch, c->bias_tab, c->tkv.base, c->rows_ident};
   for (void* b : bufs) (void)hipFree(b);
   if (c->tape) {
@@ -2573,6 +2607,14 @@ int pnpi_op_layernorm_bwd(pnpi_ctx* c, const void* x, const void* dy, int M, int
 }
 int pnpi_op_groupnorm_bwd(pnpi_ctx* c, const void* x1, const void* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                           const float* beta, int silu, const void* dy, void* dx) {
+  const int C = C1 + C2;
+  if (!(C & 7) && !(C1 & 7) && G <= 64) {      // the product path: three chip-wide phases (here with one dense destination)
+    float* ws = nullptr;
+    CKP(gn_bwd_workspace(c, B, HW, G, &ws));
+    CK(launch_groupnorm_bwd2((const half_t*)x1, (const half_t*)x2, C1, C2, B, HW, G, eps, gamma, beta, silu, (const half_t*)dy,
+                             GnbOut{(half_t*)dx, C, 0}, GnbOut{(half_t*)dx + C1, C, 0}, ws, c->st));
+    return 0;
+  }
   CK(launch_groupnorm_bwd((const half_t*)x1, (const half_t*)x2, C1, C2, B, HW, G, eps, gamma, beta, silu, (const half_t*)dy, (half_t*)dx, c->st));
   return 0;
 }

@@ -185,6 +185,7 @@ struct pnpi_ctx {
   TextKV tkv;
   // level-1 fallback for controllers without a descriptor: materialise-and-call-back (pnpi_set_attention_callback)
   pnpi_attn_callback attn_cb = nullptr;
+  float* gn_bwd_ws = nullptr; size_t gn_bwd_ws_floats = 0;   // partial sums of the three-phase GroupNorm backward (grown on demand)
   void* attn_cb_user = nullptr;
   float* attn_buf = nullptr; size_t attn_buf_bytes = 0;   // caller-owned device buffer the probabilities are materialised in
   std::unordered_map<std::string, Slot> slots;

@@ -167,6 +167,12 @@ int launch_local_blend(const float* lb_acc, int nslots, int map_hw, int lat_hw, 
 int launch_layernorm_bwd(const half_t* x, const half_t* dy, int M, int C, float eps, const float* gamma, half_t* dx, hipStream_t st);
 int launch_groupnorm_bwd(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                          const float* beta, int silu, const half_t* dy, half_t* dx, hipStream_t st);
+// Three chip-wide phases instead of one block per group; dx goes straight into the gradient buffers of the two concat sources
+// (p == nullptr: that source needs no gradient; acc: add to what is there).  scratch: groupnorm_bwd2_scratch_floats() floats.
+struct GnbOut { half_t* p; int ld; int acc; };
+size_t groupnorm_bwd2_scratch_floats(int B, int HW, int G);
+int launch_groupnorm_bwd2(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma, const float* beta,
+                          int silu, const half_t* dy, GnbOut o1, GnbOut o2, float* scratch, hipStream_t st);
 int launch_geglu_bwd(const half_t* h, const half_t* dy, int M, int I, half_t* dh, hipStream_t st);
 int launch_softmax_bwd_rows(const float* P, const float* dP, size_t R, int N, int ld, float scale, half_t* dS, hipStream_t st);
 int launch_accumulate_f16(half_t* dst, const half_t* src, size_t n, hipStream_t st);
