@@ -341,6 +341,7 @@ struct TapeOp {
   int G = 0, HW = 0, silu = 0;
   float eps = 0.f;
   const half_t *q = nullptr, *k = nullptr, *v = nullptr;                                             // attention (base tensors)
+  const float* lse = nullptr;                                                                        // [B][heads][Nq] log-sum-exp left by the forward kernel
   int ldq = 0, q_off = 0, ldk = 0, k_off = 0, ldv = 0, v_off = 0, heads = 0, Nq = 0, Nk = 0, Dp = 0, dh = 0;
   float scale = 0.f;
 };
@@ -654,15 +655,17 @@ static int transformer_fwd_tape(pnpi_ctx* c, const TransformerW& t, const half_t
   const int ldv = round_up_i(N, 8);
   half_t* vt = talloc(c, (size_t)B * hd * ldv);
   half_t* ao = talloc(c, (size_t)M * C);
+  float* lse1 = (float*)talloc(c, (size_t)B * t.heads * N * 2);       // per-query log-sum-exp for the backward kernel
   if (!c->dry) {
     for (int b = 0; b < B; ++b) CK(launch_transpose_f16(qkv + (size_t)b * N * 3 * hd + 2 * hd, 3 * hd, N, hd, vt + (size_t)b * hd * ldv, ldv, c->st));
     AttnP a; a.q = qkv; a.ldq = 3 * hd; a.q_off = 0; a.k = qkv; a.ldk = 3 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv;
     a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale; a.rows = c->cd.rows_id; a.nrows = B;
+    a.lse = lse1;
     CK(launch_attn_flash(a, c->st));
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
     if (taping(c)) {
       TapeOp o; o.kind = TK_ATTN; o.q = qkv; o.ldq = 3 * hd; o.q_off = 0; o.k = qkv; o.ldk = 3 * hd; o.k_off = hd; o.v = qkv; o.ldv = 3 * hd; o.v_off = 2 * hd;
-      o.out = ao; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = N; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B;
+      o.out = ao; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = N; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B; o.lse = lse1;
       c->tape->ops.push_back(o);
     }
   }
@@ -678,15 +681,17 @@ static int transformer_fwd_tape(pnpi_ctx* c, const TransformerW& t, const half_t
   const int ldv2 = round_up_i(T, 8);
   half_t* vt2 = talloc(c, (size_t)B * hd * ldv2);
   half_t* ao2 = talloc(c, (size_t)M * C);
+  float* lse2 = (float*)talloc(c, (size_t)B * t.heads * N * 2);
   if (!c->dry) {
     for (int b = 0; b < B; ++b) CK(launch_transpose_f16(kv2 + (size_t)b * T * 2 * hd + hd, 2 * hd, T, hd, vt2 + (size_t)b * hd * ldv2, ldv2, c->st));
     AttnP a; a.q = q2; a.ldq = hd; a.q_off = 0; a.k = kv2; a.ldk = 2 * hd; a.k_off = 0; a.vt = vt2; a.ldv = ldv2;
     a.o = ao2; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = T; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale; a.rows = c->cd.rows_id; a.nrows = B;
+    a.lse = lse2;
     CK(launch_attn_flash(a, c->st));
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * 96 * t.Dp;
     if (taping(c)) {
       TapeOp o; o.kind = TK_ATTN; o.q = q2; o.ldq = hd; o.q_off = 0; o.k = kv2; o.ldk = 2 * hd; o.k_off = 0; o.v = kv2; o.ldv = 2 * hd; o.v_off = hd;
-      o.out = ao2; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = T; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B;
+      o.out = ao2; o.ldo = C; o.heads = t.heads; o.Nq = N; o.Nk = T; o.Dp = t.Dp; o.dh = t.dh; o.scale = scale; o.B = B; o.lse = lse2;
       c->tape->ops.push_back(o);
     }
   }
@@ -915,21 +920,32 @@ static int attn_bwd_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_of
 // Self-attention backward in flash form (attn.hip: attn_bwd_flash_kernel): three transposes (K^T, Q^T, dO^T of every head), then one launch
 // each for dQ (which also leaves the per-query log-sum-exp and D), dK and dV.  Workspace per batch row: 3 * heads * dh * N halfs +
 // 2 * heads * N floats -- at the 64 x 64 level 8 MB against the 8.6 GB-per-8-heads of the score matrices.
+// cross-attention (77 keys): dK / dV have one 128-row key tile per head, so the query walk is split over workgroups (fp32 partial sums,
+// added in a fixed order by a small reduce launch)
+static int attn_bwd_flash_nsplit(int Nq, int Nk) {
+  if (Nk > 128 || Nq < 256) return 1;
+  const int n = Nq / 128;
+  return n > 32 ? 32 : n;
+}
 static size_t attn_bwd_flash_scratch_bytes(int heads, int Nq, int Nk, int dh) {
   const size_t ldk8 = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
-  return (size_t)heads * (align_up((size_t)dh * ldk8 * 2, 256) + 2 * align_up((size_t)dh * ldq8 * 2, 256) + 2 * align_up((size_t)Nq * 4, 256));
+  const int ns = attn_bwd_flash_nsplit(Nq, Nk);
+  return (size_t)heads * (align_up((size_t)dh * ldk8 * 2, 256) + 2 * align_up((size_t)dh * ldq8 * 2, 256) + 2 * align_up((size_t)Nq * 4, 256)) +
+         (ns > 1 ? align_up((size_t)ns * heads * Nk * dh * 4, 256) : 0);
 }
 static bool attn_bwd_flash_shape(int Nq, int Nk, int Dp, int dh) {
-  // cross-attention (77 keys) keeps the materialised form: its score matrices are small, and its 77 keys would put one workgroup per head
-  // in front of a 4096-query walk
-  return g_attn_bwd_flash && Nq == Nk && Nq >= 64 && Nq % 64 == 0 && (Dp == 32 || Dp == 64 || Dp == 96 || Dp == 160) && dh <= Dp && !(dh & 7);
+  // tuning "attn_bwd_flash": 0 = the materialised form everywhere, 1 = flash form for self- and cross-attention (dQ with the forward's
+  // log-sum-exp where the tape has it), 2 = the same with the two-pass dQ always, 3 = self-attention only
+  const bool self = Nq == Nk, cross = !self && Nk <= 128 && Nk >= 8;
+  if (!g_attn_bwd_flash || !(self || (cross && g_attn_bwd_flash != 3))) return false;
+  return Nq >= 64 && Nq % 64 == 0 && (Dp == 32 || Dp == 64 || Dp == 96 || Dp == 160) && dh <= Dp && !(dh & 7);
 }
 static bool attn_bwd_flash_ok(int heads, int Nq, int Nk, int Dp, int dh, size_t scratch_bytes) {
   return attn_bwd_flash_shape(Nq, Nk, Dp, dh) && scratch_bytes >= attn_bwd_flash_scratch_bytes(heads, Nq, Nk, dh);
 }
 static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp,
                           int v_off, const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B,
-                          half_t* dq, half_t* dk, half_t* dv, void* scratch) {
+                          half_t* dq, half_t* dk, half_t* dv, void* scratch, const float* lse_fwd, const half_t* o_fwd, int ld_ofwd) {
   if ((ldq & 7) || (ldk & 7) || (ldvp & 7) || (ldo & 7) || (q_off & 7) || (k_off & 7) || (v_off & 7))
     return fail(c, PNPI_ESHAPE, "attention backward: extents must be multiples of 8");
   const int ldk8 = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
@@ -939,7 +955,9 @@ static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, cons
   half_t* Qt = (half_t*)sp; sp += szQ * heads;
   half_t* dOt = (half_t*)sp; sp += szQ * heads;
   float* lse = (float*)sp; sp += szF * heads;
-  float* dsum = (float*)sp;
+  float* dsum = (float*)sp; sp += szF * heads;
+  float* part = (float*)sp;
+  const int nsplit = attn_bwd_flash_nsplit(Nq, Nk);
   if (szF != (size_t)Nq * 4) return fail(c, PNPI_ESHAPE, "attention backward: Nq * 4 must be a multiple of 256");   // [heads][Nq] dense (Nq >= 64, % 64 == 0 in every caller)
   for (int b = 0; b < B; ++b) {
     const half_t* qh = q + (size_t)b * Nq * ldq + q_off;
@@ -955,22 +973,31 @@ static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, cons
     a.heads = heads; a.scale = scale; a.lse = lse; a.dsum = dsum; a.out_hs = Dp; a.out_w = dh;
     a.b1 = mq; a.b2 = mdo; a.l1 = mk; a.l2 = mv; a.lt = tk; a.nb = Nq; a.nl = Nk;
     a.out = dq + (size_t)b * Nq * ldq + q_off; a.out_ld = ldq;
+    if (lse_fwd && o_fwd && !(ld_ofwd & 7)) {     // the recording forward left the log-sum-exp and O: dQ without its first pass over the keys
+      a.lse = const_cast<float*>(lse_fwd) + (size_t)b * heads * Nq;       // read-only in this form
+      a.o = o_fwd + (size_t)b * Nq * ld_ofwd; a.o_hs = dh; a.o_ld = ld_ofwd;
+    }
     CK(launch_attn_bwd_flash(a, 0, Dp, c->st));
+    a.o = nullptr;
     a.b1 = mk; a.b2 = mv; a.l1 = mq; a.l2 = mdo; a.lt = tq; a.nb = Nk; a.nl = Nq;
+    a.nsplit = nsplit; a.part = nsplit > 1 ? part : nullptr;
     a.out = dk + (size_t)b * Nk * ldk + k_off; a.out_ld = ldk;
     CK(launch_attn_bwd_flash(a, 1, Dp, c->st));
+    if (nsplit > 1) CK(launch_attn_bwd_reduce(a, c->st));
     a.lt = tdo;
     a.out = dv + (size_t)b * Nk * ldvp + v_off; a.out_ld = ldvp;
     CK(launch_attn_bwd_flash(a, 2, Dp, c->st));
+    if (nsplit > 1) CK(launch_attn_bwd_reduce(a, c->st));
   }
   return 0;
 }
 // dq / dk / dv of one attention site: the flash form for self-attention, the materialised form otherwise
 static int attn_bwd(pnpi_ctx* c, const half_t* q, int ldq, int q_off, const half_t* k, int ldk, int k_off, const half_t* v, int ldvp, int v_off,
                     const half_t* d_o, int ldo, int heads, int Nq, int Nk, int Dp, int dh, float scale, int B, half_t* dq, half_t* dk, half_t* dv,
-                    void* scratch, size_t scratch_bytes) {
+                    void* scratch, size_t scratch_bytes, const float* lse_fwd = nullptr, const half_t* o_fwd = nullptr, int ld_ofwd = 0) {
   if (scratch && attn_bwd_flash_ok(heads, Nq, Nk, Dp, dh, scratch_bytes))
-    return attn_bwd_flash(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch);
+    return attn_bwd_flash(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch,
+                          g_attn_bwd_flash == 2 ? nullptr : lse_fwd, o_fwd, ld_ofwd);      // tuning value 2: always the two-pass dQ
   return attn_bwd_materialized(c, q, ldq, q_off, k, ldk, k_off, v, ldvp, v_off, d_o, ldo, heads, Nq, Nk, Dp, dh, scale, B, dq, dk, dv, scratch, scratch_bytes);
 }
 static int gn_bwd_workspace(pnpi_ctx* c, int B, int HW, int G, float** out) {
@@ -1183,7 +1210,7 @@ static int tape_backward(pnpi_ctx* c, const half_t* d_out) {
         CKP(grad_of(o.v, (size_t)o.B * o.Nk * o.ldv, &gv));
         // (the projection outputs have exactly one consumer each -- this attention -- so the kernels may overwrite, not accumulate)
         CKP(attn_bwd(c, o.q, o.ldq, o.q_off, o.k, o.ldk, o.k_off, o.v, o.ldv, o.v_off, dy, ldo_eff, o.heads, o.Nq, o.Nk, o.Dp, dh_eff,
-                     o.scale, o.B, gq, gk, gv, T.attn_scratch, T.attn_scratch_bytes));
+                     o.scale, o.B, gq, gk, gv, T.attn_scratch, T.attn_scratch_bytes, pad_dh ? nullptr : o.lse, o.out, o.ldo));
         break;
       }
       default: break;

@@ -184,6 +184,8 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
   }
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
   const float inv = 1.f / ltot;
+  // recording forward of the null-text path: log2 sum_k 2^(c S) per query, for the backward kernel (mrun is the reference exponent of lrun)
+  if (p.lse && qok && h == 0) p.lse[((size_t)orow * p.heads + head) * p.Nq + qtok] = mrun * c + __log2f(ltot);
   if (qok) {
     half_t* op = p.o + ((size_t)orow * p.Nq + qtok) * p.ldo + head * p.dh;
 #pragma unroll
@@ -344,6 +346,8 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   }
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
   const float inv = 1.f / ltot;
+  // recording forward of the null-text path: log2 sum_k 2^(c S) per query, for the backward kernel (mrun is the reference exponent of lrun)
+  if (p.lse && qok && h == 0) p.lse[((size_t)orow * p.heads + head) * p.Nq + qtok] = mrun * c + __log2f(ltot);
   if (qok) {
     half_t* op = p.o + ((size_t)orow * p.Nq + qtok) * p.ldo + head * p.dh;
 #pragma unroll
@@ -688,12 +692,15 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
-  const int nbt = (p.nb + 127) >> 7, T = nbt * p.heads, per = (T + 7) >> 3;
+  const int nbt = (p.nb + 127) >> 7, T = nbt * p.heads * p.nsplit, per = (T + 7) >> 3;
   const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (tix >= T) return;
-  const int bt = tix % nbt, head = tix / nbt;
+  const int bt = tix % nbt, head = (tix / nbt) % p.heads, split = tix / (nbt * p.heads);
   const int brow = bt * 128 + wave * 32 + ql;
   const bool bok = brow < p.nb;
+  // this workgroup's share of the loop rows (everything unless the launch is split; whole LT tiles)
+  const int lchunk = ((p.nl + p.nsplit - 1) / p.nsplit + LT - 1) / LT * LT;
+  const int l_begin = split * lchunk, l_end = min(p.nl, l_begin + lchunk);
 
   half8 f1[KS], f2[KS];
   {
@@ -756,9 +763,25 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
   };
   const float c = p.scale * 1.44269504088896340736f;
   float lse2 = 0.f, dq = 0.f;
-  if constexpr (MODE == 0) {
+  if (MODE == 0 && p.o) {
+    // the forward kernel left the log-sum-exp, and D[q] = sum_k P dP = sum_d dO[q][d] O[q][d]: no first pass over the keys
+    float part = 0.f;
+    if (bok) {
+      const half_t* so = p.o + (size_t)head * p.o_hs + (size_t)brow * p.o_ld + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (ks * 16 + h * 8 < p.b2.w) {
+          const half8 ov = ldg_half8(so + ks * 16);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) part = __builtin_fmaf((float)ov[j], (float)f2[ks][j], part);
+        }
+    }
+    dq = part + __shfl_xor(part, 32, 64);
+    lse2 = bok ? p.lse[(size_t)head * p.nb + brow] : 0.f;
+    if (h == 0 && bok) p.dsum[(size_t)head * p.nb + brow] = dq;
+  } else if constexpr (MODE == 0) {
     float mrun = -INFINITY, lrun = 0.f, drun = 0.f;
-    for (int l0 = 0; l0 < p.nl; l0 += LT) {
+    for (int l0 = l_begin; l0 < l_end; l0 += LT) {
       __syncthreads();
       stage_rows(p.l1, sL1, l0);
       stage_rows(p.l2, sL2, l0);
@@ -807,7 +830,7 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
-  for (int l0 = 0; l0 < p.nl; l0 += LT) {
+  for (int l0 = l_begin; l0 < l_end; l0 += LT) {
     __syncthreads();
     stage_rows(p.l1, sL1, l0);
     if constexpr (MODE != 2) stage_rows(p.l2, sL2, l0);
@@ -848,7 +871,17 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
           acc[ot] = mfma32(vf, pf[st][t], acc[ot]);
         }
   }
-  if (bok) {
+  if (bok && p.nsplit > 1) {            // fp32 partial sums of this share of the loop rows; launch_attn_bwd_reduce adds the shares in order
+    const float osc = MODE == 2 ? 1.f : p.scale;
+    float* pp = p.part + (((size_t)split * p.heads + head) * p.nb + brow) * p.out_w;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = ot * 32 + acc_row(r, lane);
+        if (d < p.out_w) pp[d] = acc[ot][r] * osc;
+      }
+  } else if (bok) {
     const float osc = MODE == 2 ? 1.f : p.scale;
     half_t* op = p.out + (size_t)head * p.out_hs + (size_t)brow * p.out_ld;
 #pragma unroll
@@ -869,9 +902,30 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
   }
 }
 
+__global__ void __launch_bounds__(256) attn_bwd_reduce_kernel(AttnBwdP p) {
+  const size_t per = (size_t)p.heads * p.nb * p.out_w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < p.nsplit; ++sp) s += p.part[(size_t)sp * per + i];
+    const int d = (int)(i % p.out_w);
+    const size_t hr = i / p.out_w;
+    const int row = (int)(hr % p.nb), head = (int)(hr / p.nb);
+    p.out[(size_t)head * p.out_hs + (size_t)row * p.out_ld + d] = (half_t)s;
+  }
+}
+int launch_attn_bwd_reduce(const AttnBwdP& p, hipStream_t st) {
+  if (p.nsplit < 2 || !p.part) return -3;
+  const size_t per = (size_t)p.heads * p.nb * p.out_w;
+  int blocks = (int)((per + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  attn_bwd_reduce_kernel<<<blocks, 256, 0, st>>>(p);
+  return (int)hipGetLastError();
+}
+
 template <int DP, int LT>
 static int launch_abf(const AttnBwdP& p, int mode, hipStream_t st) {
-  const int T = ((p.nb + 127) >> 7) * p.heads;
+  if (p.nsplit < 1 || (p.nsplit > 1 && (mode == 0 || !p.part))) return -3;
+  const int T = ((p.nb + 127) >> 7) * p.heads * p.nsplit;
   const dim3 grid((unsigned)(((T + 7) / 8) * 8));
   if (mode == 0) attn_bwd_flash_kernel<DP, LT, 0><<<grid, 256, 0, st>>>(p);
   else if (mode == 1) attn_bwd_flash_kernel<DP, LT, 1><<<grid, 256, 0, st>>>(p);

@@ -104,6 +104,7 @@ struct AttnP {
   int nrows;
   int causal = 0;                 // 1: key j is masked for query i when j > i (CLIP text encoder)
   int vt_perm = 0;                // 1: vt is stored in the permuted key order (only the 64-wide LDS-DMA self-attention kernel reads it)
+  float* lse = nullptr;           // optional [out_row][heads][Nq]: log2-domain log-sum-exp of every query (recording forward of the null-text path)
 };
 int launch_attn_flash(const AttnP& p, hipStream_t st);
 bool attn_flash_uses_dma64(int Dp, int Nk, int causal);
@@ -119,7 +120,12 @@ struct AttnBwdP {
   float* lse;                     // [heads][queries] log2-domain log-sum-exp: written by DQ, read by DK / DV
   float* dsum;                    // [heads][queries] sum_k P dP                   (same)
   half_t* out; long out_hs; int out_ld, out_w;   // out[head * out_hs + block_row * out_ld + d], d < out_w
-};
+  const half_t* o = nullptr; long o_hs = 0; int o_ld = 0;   // DQ only, optional: the forward's output O (head * o_hs + query * o_ld + d) -- with it
+                                  // `lse` is an INPUT (the forward kernel's) and D = rowsum(dO o O): the kernel's first pass over the keys is skipped
+  int nsplit = 1;                 // DK / DV with few keys (cross-attention): the loop rows are split over nsplit workgroups per (key tile, head), each
+  float* part = nullptr;          // writing fp32 partial sums part[((split * heads + head) * nb + block_row) * out_w + d]; summed in order by
+};                                // launch_attn_bwd_reduce
+int launch_attn_bwd_reduce(const AttnBwdP& p, hipStream_t st);
 int launch_attn_bwd_flash(const AttnBwdP& p, int mode /*0 DQ, 1 DK, 2 DV*/, int Dp, hipStream_t st);   // -1: head width not instantiated
 
 // Cross-attention with the Prompt-to-Prompt edit fused in (one (src,tgt) row pair per grid.z entry).

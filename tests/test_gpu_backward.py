@@ -186,11 +186,14 @@ def test_attention_bwd_materialised(ctx, B, heads, Nq, Nk, dh, Dp):
         assert rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref) < 6e-3, rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref)
 
 
-@pytest.mark.parametrize("B,heads,Nq,dh,Dp", [(1, 8, 1024, 40, 64), (2, 4, 1024, 80, 96), (1, 4, 256, 160, 160), (1, 2, 4096, 40, 64),
-                                              (1, 2, 64, 8, 32), (2, 3, 192, 40, 64)])
-def test_attention_bwd_flash(ctx, B, heads, Nq, dh, Dp):
-    """Self-attention backward in flash form (no [N][N] matrices in memory: attn_bwd_flash_kernel, three modes) against autograd and
-    against the materialised form (tuning attn_bwd_flash = 0) on the same inputs; 192 = one and a half 128-row workgroups."""
+@pytest.mark.parametrize("B,heads,Nq,Nk,dh,Dp", [(1, 8, 1024, 0, 40, 64), (2, 4, 1024, 0, 80, 96), (1, 4, 256, 0, 160, 160), (1, 2, 4096, 0, 40, 64),
+                                                 (1, 2, 64, 0, 8, 32), (2, 3, 192, 0, 40, 64),
+                                                 (1, 8, 4096, 77, 40, 64), (2, 4, 1024, 77, 80, 96), (1, 4, 256, 77, 160, 160), (1, 2, 64, 77, 160, 160)])
+def test_attention_bwd_flash(ctx, B, heads, Nq, Nk, dh, Dp):
+    """Attention backward in flash form (no [N][N] matrices in memory: attn_bwd_flash_kernel, three modes) against autograd and against the
+    materialised form (tuning attn_bwd_flash = 0) on the same inputs.  Nk = 0: self-attention (192 = one and a half 128-row workgroups);
+    Nk = 77: cross-attention, whose dK / dV walk over the queries is split over workgroups and summed in a fixed order."""
+    Nk = Nk or Nq
     g = torch.Generator(device="cpu").manual_seed(23)
     scale = 1.0 / math.sqrt(dh)
 
@@ -199,19 +202,19 @@ def test_attention_bwd_flash(ctx, B, heads, Nq, dh, Dp):
         t[..., :dh] = torch.randn(B, n, heads, dh, generator=g) * amp
         return t.reshape(B * n, heads * Dp).half().to(DEV)
 
-    q, k, v = padded(Nq, 1.5), padded(Nq, 1.5), padded(Nq)               # amp 1.5: peaked rows as well as flat ones
+    q, k, v = padded(Nq, 1.5), padded(Nk, 1.5), padded(Nk)               # amp 1.5: peaked rows as well as flat ones
     d_o = torch.randn(B * Nq, heads * dh, generator=g).half().to(DEV)
     qr, kr, vr = [t.float().reshape(B, -1, heads, Dp)[..., :dh].permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v)]
     o = torch.softmax(scale * qr @ kr.transpose(-1, -2), -1) @ vr
     o.backward(d_o.float().reshape(B, Nq, heads, dh).permute(0, 2, 1, 3))
-    nbytes = ctx.lib.pnpi_op_attention_bwd_scratch_bytes(Nq, Nq, dh) * heads
+    nbytes = ctx.lib.pnpi_op_attention_bwd_scratch_bytes(Nq, Nk, dh) * heads + (64 << 20)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     got = {}
     try:
         for flash in (1, 0):
             assert ctx.lib.pnpi_set_tuning(b"attn_bwd_flash", flash) == 0
             dq, dk, dv = [torch.zeros_like(t) for t in (q, k, v)]
-            ctx.call("pnpi_op_attention_bwd", ptr(q), heads * Dp, 0, ptr(k), heads * Dp, 0, ptr(v), heads * Dp, 0, ptr(d_o), heads * dh, heads, Nq, Nq, Dp,
+            ctx.call("pnpi_op_attention_bwd", ptr(q), heads * Dp, 0, ptr(k), heads * Dp, 0, ptr(v), heads * Dp, 0, ptr(d_o), heads * dh, heads, Nq, Nk, Dp,
                      dh, scale, B, ptr(dq), ptr(dk), ptr(dv), ptr(scratch), nbytes)
             torch.cuda.synchronize()
             got[flash] = (dq, dk, dv)
@@ -219,7 +222,7 @@ def test_attention_bwd_flash(ctx, B, heads, Nq, dh, Dp):
         ctx.lib.pnpi_set_tuning(b"attn_bwd_flash", 1)
     for name, i, ref in (("dq", 0, qr.grad), ("dk", 1, kr.grad), ("dv", 2, vr.grad)):
         for flash in (1, 0):
-            gh = got[flash][i].float().reshape(B, Nq, heads, Dp)
+            gh = got[flash][i].float().reshape(B, Nq if i == 0 else Nk, heads, Dp)
             assert (gh[..., dh:] == 0).all(), (name, flash)                                # pad columns untouched
             e = rel_err(gh[..., :dh].permute(0, 2, 1, 3), ref)
             assert e < 6e-3, (name, flash, e)
@@ -227,6 +230,34 @@ def test_attention_bwd_flash(ctx, B, heads, Nq, dh, Dp):
         a, b = got[1][i].float(), got[0][i].float()
         assert not torch.equal(a, torch.zeros_like(a))
         assert rel_err(a, b) < 4e-3, (name, rel_err(a, b))
+
+
+def test_context_gradient_same_with_forward_lse_and_two_pass_dq():
+    """The reverse walk hands the dQ kernel the log-sum-exp the recording forward's flash kernels left and the attention output O
+    (D = rowsum(dO o O)), so its first pass over the keys is skipped; tuning attn_bwd_flash = 2 makes it recompute both, 0 takes the
+    materialised form: three programs, one gradient (SMALL64: dh = 8, every attention site 64 .. 4096 queries)."""
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import SMALL64
+    from pnpinversion_amd.engine import NativeEngine
+    cfg = SMALL64
+    eng = NativeEngine(cfg, max_unet_rows=4, max_vae_images=1)
+    eng.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    g = torch.Generator().manual_seed(41)
+    lat = torch.randn(1, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g).cuda()
+    ctx = weights.synth_context(cfg, 1, seed=42).cuda()
+    d_eps = (torch.randn(1, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g) * 256).cuda()
+    got = {}
+    try:
+        for mode in (1, 2, 0):
+            assert eng.lib.pnpi_set_tuning(b"attn_bwd_flash", mode) == 0
+            eps, dctx = eng.unet_context_grad(lat, 500, ctx, d_eps)
+            got[mode] = (eps.clone(), dctx.clone())
+    finally:
+        eng.lib.pnpi_set_tuning(b"attn_bwd_flash", 1)
+        eng.close()
+    assert torch.equal(got[1][0], got[2][0]) and torch.isfinite(got[1][1]).all() and got[1][1].abs().max() > 0
+    assert rel_err(got[1][1], got[2][1]) < 1e-2, rel_err(got[1][1], got[2][1])
+    assert rel_err(got[1][1], got[0][1]) < 1e-2, rel_err(got[1][1], got[0][1])
 
 
 # ------------------------------------------------------------------------------------------------ whole-UNet context gradient, null-text loop
