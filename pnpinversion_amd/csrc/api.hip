@@ -1040,6 +1040,15 @@ static int tape_add_strided(pnpi_ctx* c, const void* key, const half_t* src, int
   Tape& T = *c->tape;
   auto it = T.grads.find(key);
   if (it == T.grads.end()) {
+    // First contribution from a dense buffer of this backward's own arena (a dgrad result, or the finished gradient of the op's output on
+    // its way into a residual branch): the buffer BECOMES the gradient -- no copy.  Safe because the walk is in reverse order: the source
+    // is either fresh or the gradient of an activation whose consumers have all been processed, and later contributions are stream-ordered
+    // behind this op's own reads of it.
+    const char* sb = (const char*)src;
+    if (ld == C && off == 0 && !T.garena.overflow && sb >= T.garena.base && sb + R * C * sizeof(half_t) <= T.garena.base + T.garena.cap) {
+      T.grads[key] = const_cast<half_t*>(src);
+      return 0;
+    }
     half_t* p = tape_galloc(c, R * C);
     if (!p) return fail(c, PNPI_ENOMEM, "gradient arena overflow");
     T.grads[key] = p;
