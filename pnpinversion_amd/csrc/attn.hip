@@ -681,7 +681,7 @@ int launch_attn_cross_edit(const CrossEditP& p, hipStream_t st) {
 // writer and a fixed summation order: deterministic.  10 tile products per (query tile, key tile) pair against the 5 of the
 // materialised form -- the price of no atomics and no second workspace.
 // ------------------------------------------------------------------------------------------------------------------
-template <int DP, int LT, int MODE>
+template <int DP, int LT, int MODE, bool PF = false>
 __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
   constexpr int KS = DP / 16, OT = DP / 32, NT = LT / 32;
   constexpr int SK_LD = DP + 8, LT_LD = LT + 4;
@@ -830,11 +830,66 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
+  // PF (the 64-wide heads of the 4096-token sites, one workgroup per CU): the next tile's global loads are issued into registers right after
+  // this tile was published in LDS and fly under its MFMAs -- without it every tile pays a full global round trip between two barriers.
+  constexpr int NVR = LT * (DP / 8) / 256, NVT = DP * (LT / 8) / 256;
+  static_assert(!PF || (LT * (DP / 8) % 256 == 0 && DP * (LT / 8) % 256 == 0), "prefetch: whole vectors per thread");
+  half8 r1[PF ? NVR : 1], r2[PF ? NVR : 1], rt[PF ? NVT : 1];
+  auto gload = [&](int l0) {
+    auto rows = [&](const BwdMat& M, half8* dst) {
+#pragma unroll
+      for (int i = 0; i < NVR; ++i) {
+        const int idx = tid + i * 256, r = idx / (DP / 8), v = idx - r * (DP / 8);
+        const int row = l0 + r;
+        dst[i] = (row < p.nl && v * 8 < M.w) ? ldg_half8(M.p + (size_t)head * M.hs + (size_t)row * M.ld + v * 8) : zero_half8();
+      }
+    };
+    rows(p.l1, r1);
+    if constexpr (MODE != 2) rows(p.l2, r2);
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+      const int idx = tid + i * 256, d = idx / (LT / 8), v = idx - d * (LT / 8);
+      const int r0 = l0 + v * 8;
+      half8 val = zero_half8();
+      if (d < p.lt.w) {
+        const half_t* src = p.lt.p + (size_t)head * p.lt.hs + (size_t)d * p.lt.ld + r0;
+        if (r0 + 8 <= p.nl) {
+          val = ldg_half8(src);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (r0 + j < p.nl) val[j] = src[j];
+        }
+      }
+      rt[i] = val;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) {
+      const int idx = tid + i * 256, r = idx / (DP / 8), v = idx - r * (DP / 8);
+      *reinterpret_cast<half8*>(sL1 + r * SK_LD + v * 8) = r1[i];
+      if constexpr (MODE != 2) *reinterpret_cast<half8*>(sL2 + r * SK_LD + v * 8) = r2[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+      const int idx = tid + i * 256, d = idx / (LT / 8), v = idx - d * (LT / 8);
+      const half8 val = rt[i];
+      half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
+      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8) = lo;
+      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8 + 4) = hi;
+    }
+  };
+  if constexpr (PF) gload(l_begin);
   for (int l0 = l_begin; l0 < l_end; l0 += LT) {
     __syncthreads();
-    stage_rows(p.l1, sL1, l0);
-    if constexpr (MODE != 2) stage_rows(p.l2, sL2, l0);
-    stage_t(l0);
+    if constexpr (PF) {
+      sstore();
+    } else {
+      stage_rows(p.l1, sL1, l0);
+      if constexpr (MODE != 2) stage_rows(p.l2, sL2, l0);
+      stage_t(l0);
+    }
     if constexpr (MODE != 0) {
       if (tid < LT) {
         const int row = l0 + tid;
@@ -843,6 +898,7 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
       }
     }
     __syncthreads();
+    if constexpr (PF) { if (l0 + LT < l_end) gload(l0 + LT); }
     tiles();
     half8 pf[NT][2];
 #pragma unroll
@@ -922,11 +978,22 @@ int launch_attn_bwd_reduce(const AttnBwdP& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static int g_abf_prefetch = 1;     // PNPI_ABF_PREFETCH=0: never the register-prefetch variant (A/B)
 template <int DP, int LT>
 static int launch_abf(const AttnBwdP& p, int mode, hipStream_t st) {
   if (p.nsplit < 1 || (p.nsplit > 1 && (mode == 0 || !p.part))) return -3;
   const int T = ((p.nb + 127) >> 7) * p.heads * p.nsplit;
   const dim3 grid((unsigned)(((T + 7) / 8) * 8));
+  static const bool pf_on = !(getenv("PNPI_ABF_PREFETCH") && atoi(getenv("PNPI_ABF_PREFETCH")) == 0);
+  if constexpr (DP == 64 || DP == 96) {
+    // many loop tiles per workgroup and at most ~one workgroup per CU: prefetch the next tile into registers
+    if (pf_on && g_abf_prefetch && p.nl >= 8 * LT && T <= 512) {
+      if (mode == 0) attn_bwd_flash_kernel<DP, LT, 0, true><<<grid, 256, 0, st>>>(p);
+      else if (mode == 1) attn_bwd_flash_kernel<DP, LT, 1, true><<<grid, 256, 0, st>>>(p);
+      else attn_bwd_flash_kernel<DP, LT, 2, true><<<grid, 256, 0, st>>>(p);
+      return (int)hipGetLastError();
+    }
+  }
   if (mode == 0) attn_bwd_flash_kernel<DP, LT, 0><<<grid, 256, 0, st>>>(p);
   else if (mode == 1) attn_bwd_flash_kernel<DP, LT, 1><<<grid, 256, 0, st>>>(p);
   else attn_bwd_flash_kernel<DP, LT, 2><<<grid, 256, 0, st>>>(p);
