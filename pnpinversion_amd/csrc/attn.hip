@@ -215,7 +215,9 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnP p) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <bool VPERM>
+// KSQ: 16-wide k-steps of S = K Q^T actually run -- 3 when the head is at most 48 wide (d = 40: columns 48 .. 63 of q and k are zero
+// padding, their products exact zeros): a quarter of the S MFMAs and K fragment reads, bit-identical results.
+template <bool VPERM, int KSQ = 4>
 __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   constexpr int DP = 64, KS = 4, OT = 2;
   constexpr int STAGE = 2 * 64 * 128;   // K tile + V^T tile, bytes
@@ -235,11 +237,11 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   const int qtok = qt * 128 + wave * 32 + ql;
   const bool qok = qtok < p.Nq;
 
-  half8 qf[KS];
+  half8 qf[KSQ];
   {
     const half_t* qp = p.q + ((size_t)qrow * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
+    for (int ks = 0; ks < KSQ; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
   }
   floatx16 O[OT];
 #pragma unroll
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KSQ; ++ks) {
         half8 kf = *reinterpret_cast<const half8*>(sK + st * 4096 + (((ks * 2 + h) ^ x7) * 16));
         s[st] = mfma32(kf, qf[ks], s[st]);
       }
@@ -381,8 +383,14 @@ int launch_attn_flash(const AttnP& p, hipStream_t st) {
   dim3 grid((unsigned)(((total + 7) / 8) * 8), 1, 1);
   static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
   if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma && !p.causal) {
-    if (p.vt_perm) attn_flash_dma64_kernel<true><<<grid, 256, 0, st>>>(p);
-    else attn_flash_dma64_kernel<false><<<grid, 256, 0, st>>>(p);
+    static const bool ksq3 = !(getenv("PNPI_ATTN_KSQ4") != nullptr);      // PNPI_ATTN_KSQ4: always four k-steps (A/B)
+    if (p.dh <= 48 && ksq3) {
+      if (p.vt_perm) attn_flash_dma64_kernel<true, 3><<<grid, 256, 0, st>>>(p);
+      else attn_flash_dma64_kernel<false, 3><<<grid, 256, 0, st>>>(p);
+    } else {
+      if (p.vt_perm) attn_flash_dma64_kernel<true><<<grid, 256, 0, st>>>(p);
+      else attn_flash_dma64_kernel<false><<<grid, 256, 0, st>>>(p);
+    }
     return (int)hipGetLastError();
   }
   if (p.vt_perm) return -6;        // only the kernel above reads the permuted layout
