@@ -169,10 +169,10 @@ def test_local_blend_substruct_words_match_reference():
     assert rel(out[1], g["edited_latents_no_substruct"][1]) > 0.5
 
 
-# four of the six golden variants run here (each turns a different knob; the CPU suite has to stay within minutes); all six
-# are checked against the HIP path in tests/test_gpu_loops.py
-VARIANTS = ["negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5", "ablation_directinversion_interval_2+p2p",
-            "ablation_directinversion_add-target+p2p"]
+# two of the six golden variants run here by default, four with PNPI_SLOW_TESTS=1 (each turns a different knob; the CPU suite has to stay
+# within minutes); all six are checked against the HIP path in tests/test_gpu_loops.py
+VARIANTS = ["negative-prompt-inversion+p2p", "directinversion+p2p_guidance_25_5"] + (
+    ["ablation_directinversion_interval_2+p2p", "ablation_directinversion_add-target+p2p"] if SLOW else [])
 
 
 @pytest.mark.parametrize("method", VARIANTS)
