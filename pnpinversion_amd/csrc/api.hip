@@ -917,9 +917,9 @@ static int attn_bwd_materialized(pnpi_ctx* c, const half_t* q, int ldq, int q_of
     }
   return 0;
 }
-// Self-attention backward in flash form (attn.hip: attn_bwd_flash_kernel): three transposes (K^T, Q^T, dO^T of every head), then one launch
-// each for dQ (which also leaves the per-query log-sum-exp and D), dK and dV.  Workspace per batch row: 3 * heads * dh * N halfs +
-// 2 * heads * N floats -- at the 64 x 64 level 8 MB against the 8.6 GB-per-8-heads of the score matrices.
+// Attention backward in flash form (attn.hip: attn_bwd_flash_kernel): one launch each for dQ (which also leaves D, and the per-query
+// log-sum-exp unless the forward did), dK and dV.  Workspace per batch row: 2 * heads * N floats (+ the fp32 partial sums of a split
+// cross-attention walk) -- at the 64 x 64 level 260 KB against the 8.6 GB-per-8-heads of the score matrices.
 // cross-attention (77 keys): dK / dV have one 128-row key tile per head, so the query walk is split over workgroups (fp32 partial sums,
 // added in a fixed order by a small reduce launch)
 static int attn_bwd_flash_nsplit(int Nq, int Nk) {
@@ -928,10 +928,8 @@ static int attn_bwd_flash_nsplit(int Nq, int Nk) {
   return n > 32 ? 32 : n;
 }
 static size_t attn_bwd_flash_scratch_bytes(int heads, int Nq, int Nk, int dh) {
-  const size_t ldk8 = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
   const int ns = attn_bwd_flash_nsplit(Nq, Nk);
-  return (size_t)heads * (align_up((size_t)dh * ldk8 * 2, 256) + 2 * align_up((size_t)dh * ldq8 * 2, 256) + 2 * align_up((size_t)Nq * 4, 256)) +
-         (ns > 1 ? align_up((size_t)ns * heads * Nk * dh * 4, 256) : 0);
+  return (size_t)heads * 2 * align_up((size_t)Nq * 4, 256) + (ns > 1 ? align_up((size_t)ns * heads * Nk * dh * 4, 256) : 0);
 }
 static bool attn_bwd_flash_shape(int Nq, int Nk, int Dp, int dh) {
   // tuning "attn_bwd_flash": 0 = the materialised form everywhere, 1 = flash form for self- and cross-attention (dQ with the forward's
@@ -948,12 +946,8 @@ static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, cons
                           half_t* dq, half_t* dk, half_t* dv, void* scratch, const float* lse_fwd, const half_t* o_fwd, int ld_ofwd) {
   if ((ldq & 7) || (ldk & 7) || (ldvp & 7) || (ldo & 7) || (q_off & 7) || (k_off & 7) || (v_off & 7))
     return fail(c, PNPI_ESHAPE, "attention backward: extents must be multiples of 8");
-  const int ldk8 = round_up_i(Nk, 8), ldq8 = round_up_i(Nq, 8);
-  const size_t szK = align_up((size_t)dh * ldk8 * 2, 256), szQ = align_up((size_t)dh * ldq8 * 2, 256), szF = align_up((size_t)Nq * 4, 256);
+  const size_t szF = align_up((size_t)Nq * 4, 256);
   char* sp = (char*)scratch;
-  half_t* Kt = (half_t*)sp; sp += szK * heads;
-  half_t* Qt = (half_t*)sp; sp += szQ * heads;
-  half_t* dOt = (half_t*)sp; sp += szQ * heads;
   float* lse = (float*)sp; sp += szF * heads;
   float* dsum = (float*)sp; sp += szF * heads;
   float* part = (float*)sp;
@@ -964,14 +958,10 @@ static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, cons
     const half_t* kh = k + (size_t)b * Nk * ldk + k_off;
     const half_t* vh = v + (size_t)b * Nk * ldvp + v_off;
     const half_t* doh = d_o + (size_t)b * Nq * ldo;
-    CK(launch_transpose_f16(kh, ldk, Nk, dh, Kt, ldk8, c->st, heads, Dp, (long)(szK / 2)));
-    CK(launch_transpose_f16(qh, ldq, Nq, dh, Qt, ldq8, c->st, heads, Dp, (long)(szQ / 2)));
-    CK(launch_transpose_f16(doh, ldo, Nq, dh, dOt, ldq8, c->st, heads, dh, (long)(szQ / 2)));
     const BwdMat mq{qh, Dp, ldq, dh}, mk{kh, Dp, ldk, dh}, mv{vh, Dp, ldvp, dh}, mdo{doh, dh, ldo, dh};
-    const BwdMat tk{Kt, (long)(szK / 2), ldk8, dh}, tq{Qt, (long)(szQ / 2), ldq8, dh}, tdo{dOt, (long)(szQ / 2), ldq8, dh};
     AttnBwdP a{};
     a.heads = heads; a.scale = scale; a.lse = lse; a.dsum = dsum; a.out_hs = Dp; a.out_w = dh;
-    a.b1 = mq; a.b2 = mdo; a.l1 = mk; a.l2 = mv; a.lt = tk; a.nb = Nq; a.nl = Nk;
+    a.b1 = mq; a.b2 = mdo; a.l1 = mk; a.l2 = mv; a.nb = Nq; a.nl = Nk;
     a.out = dq + (size_t)b * Nq * ldq + q_off; a.out_ld = ldq;
     if (lse_fwd && o_fwd && !(ld_ofwd & 7)) {     // the recording forward left the log-sum-exp and O: dQ without its first pass over the keys
       a.lse = const_cast<float*>(lse_fwd) + (size_t)b * heads * Nq;       // read-only in this form
@@ -979,12 +969,11 @@ static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, cons
     }
     CK(launch_attn_bwd_flash(a, 0, Dp, c->st));
     a.o = nullptr;
-    a.b1 = mk; a.b2 = mv; a.l1 = mq; a.l2 = mdo; a.lt = tq; a.nb = Nk; a.nl = Nq;
+    a.b1 = mk; a.b2 = mv; a.l1 = mq; a.l2 = mdo; a.nb = Nk; a.nl = Nq;
     a.nsplit = nsplit; a.part = nsplit > 1 ? part : nullptr;
     a.out = dk + (size_t)b * Nk * ldk + k_off; a.out_ld = ldk;
     CK(launch_attn_bwd_flash(a, 1, Dp, c->st));
     if (nsplit > 1) CK(launch_attn_bwd_reduce(a, c->st));
-    a.lt = tdo;
     a.out = dv + (size_t)b * Nk * ldvp + v_off; a.out_ld = ldvp;
     CK(launch_attn_bwd_flash(a, 2, Dp, c->st));
     if (nsplit > 1) CK(launch_attn_bwd_reduce(a, c->st));

@@ -721,34 +721,20 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
       for (int ks = 0; ks < KS; ++ks) f2[ks] = (bok && ks * 16 + h * 8 < p.b2.w) ? ldg_half8(s2 + ks * 16) : zero_half8();
     }
   }
-  auto stage_rows = [&](const BwdMat& M, half_t* dst, int l0) {
+  // The transposed loop-side operand (K^T for dQ, Q^T for dK, dO^T for dV) is the transpose of a row-major tile this workgroup loads
+  // anyway: it is written to LDS a second time, element-wise, as [d][row] (no transposed copies in memory, no transpose launches).
+  auto put_t = [&](const half8& val, int r, int v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sLT[(v * 8 + j) * LT_LD + r] = val[j];
+  };
+  auto stage_rows = [&](const BwdMat& M, half_t* dst, int l0, bool rows, bool tr) {
     constexpr int NV = LT * (DP / 8);
     for (int idx = tid; idx < NV; idx += 256) {
       const int r = idx / (DP / 8), v = idx - r * (DP / 8);
       const int row = l0 + r;
       const half8 val = (row < p.nl && v * 8 < M.w) ? ldg_half8(M.p + (size_t)head * M.hs + (size_t)row * M.ld + v * 8) : zero_half8();
-      *reinterpret_cast<half8*>(dst + r * SK_LD + v * 8) = val;
-    }
-  };
-  auto stage_t = [&](int l0) {
-    constexpr int NV = DP * (LT / 8);
-    for (int idx = tid; idx < NV; idx += 256) {
-      const int d = idx / (LT / 8), v = idx - d * (LT / 8);
-      const int r0 = l0 + v * 8;
-      half8 val = zero_half8();
-      if (d < p.lt.w) {
-        const half_t* src = p.lt.p + (size_t)head * p.lt.hs + (size_t)d * p.lt.ld + r0;
-        if (r0 + 8 <= p.nl) {
-          val = ldg_half8(src);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (r0 + j < p.nl) val[j] = src[j];
-        }
-      }
-      half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
-      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8) = lo;
-      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8 + 4) = hi;
+      if (rows) *reinterpret_cast<half8*>(dst + r * SK_LD + v * 8) = val;
+      if (tr) put_t(val, r, v);
     }
   };
   floatx16 s[NT], dp[NT];
@@ -791,8 +777,8 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
     float mrun = -INFINITY, lrun = 0.f, drun = 0.f;
     for (int l0 = l_begin; l0 < l_end; l0 += LT) {
       __syncthreads();
-      stage_rows(p.l1, sL1, l0);
-      stage_rows(p.l2, sL2, l0);
+      stage_rows(p.l1, sL1, l0, true, false);
+      stage_rows(p.l2, sL2, l0, true, false);
       __syncthreads();
       tiles();
       if (l0 + LT > p.nl) {
@@ -840,9 +826,9 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
     for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
   // PF (the 64-wide heads of the 4096-token sites, one workgroup per CU): the next tile's global loads are issued into registers right after
   // this tile was published in LDS and fly under its MFMAs -- without it every tile pays a full global round trip between two barriers.
-  constexpr int NVR = LT * (DP / 8) / 256, NVT = DP * (LT / 8) / 256;
-  static_assert(!PF || (LT * (DP / 8) % 256 == 0 && DP * (LT / 8) % 256 == 0), "prefetch: whole vectors per thread");
-  half8 r1[PF ? NVR : 1], r2[PF ? NVR : 1], rt[PF ? NVT : 1];
+  constexpr int NVR = LT * (DP / 8) / 256;
+  static_assert(!PF || LT * (DP / 8) % 256 == 0, "prefetch: whole vectors per thread");
+  half8 r1[PF ? NVR : 1], r2[PF ? NVR : 1];       // r2: V (dQ) / dO (dK, dV) rows
   auto gload = [&](int l0) {
     auto rows = [&](const BwdMat& M, half8* dst) {
 #pragma unroll
@@ -853,24 +839,7 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
       }
     };
     rows(p.l1, r1);
-    if constexpr (MODE != 2) rows(p.l2, r2);
-#pragma unroll
-    for (int i = 0; i < NVT; ++i) {
-      const int idx = tid + i * 256, d = idx / (LT / 8), v = idx - d * (LT / 8);
-      const int r0 = l0 + v * 8;
-      half8 val = zero_half8();
-      if (d < p.lt.w) {
-        const half_t* src = p.lt.p + (size_t)head * p.lt.hs + (size_t)d * p.lt.ld + r0;
-        if (r0 + 8 <= p.nl) {
-          val = ldg_half8(src);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (r0 + j < p.nl) val[j] = src[j];
-        }
-      }
-      rt[i] = val;
-    }
+    rows(p.l2, r2);
   };
   auto sstore = [&]() {
 #pragma unroll
@@ -878,14 +847,7 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
       const int idx = tid + i * 256, r = idx / (DP / 8), v = idx - r * (DP / 8);
       *reinterpret_cast<half8*>(sL1 + r * SK_LD + v * 8) = r1[i];
       if constexpr (MODE != 2) *reinterpret_cast<half8*>(sL2 + r * SK_LD + v * 8) = r2[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NVT; ++i) {
-      const int idx = tid + i * 256, d = idx / (LT / 8), v = idx - d * (LT / 8);
-      const half8 val = rt[i];
-      half4 lo = {val[0], val[1], val[2], val[3]}, hi = {val[4], val[5], val[6], val[7]};
-      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8) = lo;
-      *reinterpret_cast<half4*>(sLT + d * LT_LD + v * 8 + 4) = hi;
+      put_t(MODE == 2 ? r2[i] : r1[i], r, v);
     }
   };
   if constexpr (PF) gload(l_begin);
@@ -894,9 +856,8 @@ __global__ void __launch_bounds__(256) attn_bwd_flash_kernel(AttnBwdP p) {
     if constexpr (PF) {
       sstore();
     } else {
-      stage_rows(p.l1, sL1, l0);
-      if constexpr (MODE != 2) stage_rows(p.l2, sL2, l0);
-      stage_t(l0);
+      stage_rows(p.l1, sL1, l0, true, MODE != 2);
+      stage_rows(p.l2, sL2, l0, MODE != 2, MODE == 2);
     }
     if constexpr (MODE != 0) {
       if (tid < LT) {

@@ -113,8 +113,8 @@ bool attn_flash_uses_dma64(int Dp, int Nk, int causal);
 struct BwdMat { const half_t* p; long hs; int ld; int w; };   // (head, row, col) -> p[head * hs + row * ld + col]; columns >= w read as zero (w % 8 == 0)
 struct AttnBwdP {
   BwdMat b1, b2;                  // the workgroup's own ("block") rows, held in registers: DQ: Q, dO;  DK: K, V;  DV: K
-  BwdMat l1, l2;                  // the rows it walks ("loop" side, staged in LDS):        DQ: K, V;   DK: Q, dO; DV: Q
-  BwdMat lt;                      // loop side TRANSPOSED, (head, d, row) -> p[head * hs + d * ld + row], rows d >= w read as zero: DQ: K^T; DK: Q^T; DV: dO^T
+  BwdMat l1, l2;                  // the rows it walks ("loop" side, staged in LDS):        DQ: K, V;   DK: Q, dO; DV: Q, dO
+                                  // (the transposed operand of the accumulation -- K^T, Q^T, dO^T -- is made from these tiles in LDS)
   int nb, nl, heads;              // block rows, loop rows
   float scale;
   float* lse;                     // [heads][queries] log2-domain log-sum-exp: written by DQ, read by DK / DV
