@@ -968,6 +968,8 @@ static int attn_bwd_flash(pnpi_ctx* c, const half_t* q, int ldq, int q_off, cons
       a.o = o_fwd + (size_t)b * Nq * ld_ofwd; a.o_hs = dh; a.o_ld = ld_ofwd;
     }
     CK(launch_attn_bwd_flash(a, 0, Dp, c->st));
+    // tile products of the three launches (dQ: S, dP, dQ -- twice S and dP without the forward's log-sum-exp; dK: S, dP, dK; dV: S, dV)
+    c->ctr.executed_attn_flops += 2.0 * heads * (double)Nq * Nk * Dp * ((a.o ? 3 : 5) + 3 + 2);
     a.o = nullptr;
     a.b1 = mk; a.b2 = mv; a.l1 = mq; a.l2 = mdo; a.nb = Nk; a.nl = Nq;
     a.nsplit = nsplit; a.part = nsplit > 1 ? part : nullptr;
