@@ -2,7 +2,9 @@
 igemm_force_cfg / igemm_force_split), per-launch HIP-event times collected from the profile dump and summed per layer shape.
 Unlike tools/autotune2.py (one GEMM in a loop, operands warm in the 256 MB MALL) this times each shape with the epilogue it really
 has (residual, GEGLU, GroupNorm statistics, V^T) and the cache state it really meets inside a forward.
-usage: fwd_tune.py [rows ...] (default 12 1) -> gpurun_out/fwd_tune_b<rows>.json (the format tools/gen_tile_table.py reads)"""
+usage: fwd_tune.py [rows ...] (default 12 1) -> gpurun_out/fwd_tune_b<rows>.json (the format tools/gen_tile_table.py reads)
+FWD_TUNE_WORK=ctxgrad (rows = 1): the workload is one recording forward + reverse walk (pnpi_unet_context_grad, the null-text iteration), so
+the dgrad shapes of the walk are tuned too -> gpurun_out/fwd_tune_b1bwd.json"""
 import csv, json, os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pnpinversion_amd import weights
@@ -22,8 +24,12 @@ os.makedirs("gpurun_out", exist_ok=True)
 dump = "gpurun_out/_fwd_tune_dump.csv"
 os.environ["PNPI_PROFILE_DUMP"] = dump
 NF = 3
+BWD = os.environ.get("FWD_TUNE_WORK") == "ctxgrad"
+if BWD: rows_list = [1]
 for rows in rows_list:
     lat = torch.randn(rows, 4, 64, 64, device="cuda"); ctx = torch.randn(rows, 77, 768, device="cuda")
+    d_eps = torch.randn(rows, 4, 64, 64, device="cuda") * 256
+    work = (lambda: eng.unet_context_grad(lat, 500, ctx, d_eps)) if BWD else (lambda: eng.unet(lat, 500, None))
     eng.text_kv_precompute(ctx)
     combos = [(-1, 0)] + [(c, 0) for c in SINGLE] + [(c, s) for s in SPLITS for c in SPLIT_CFGS]
     if os.environ.get("FWD_TUNE_CFGS"):        # quick look at a few configurations: FWD_TUNE_CFGS="3,14"
@@ -33,9 +39,9 @@ for rows in rows_list:
     total = {}
     for cfg, split in combos:
         setk(igemm_force_cfg=cfg, igemm_force_split=split)
-        eng.unet(lat, 500, None)
+        work()
         eng.profile_begin()
-        for _ in range(NF): eng.unet(lat, 500, None)
+        for _ in range(NF): work()
         eng.profile_end()
         per = collections.defaultdict(float); n = collections.defaultdict(int); tot = 0.0
         for r in csv.DictReader(open(dump)):
@@ -62,4 +68,4 @@ for rows in rows_list:
     for s in sorted(shapes, key=lambda s: -(s["us"].get("auto", 0) - min(v for k, v in s["us"].items() if k != "auto")))[:12]:
         b = min(((k, v) for k, v in s["us"].items() if k != "auto"), key=lambda kv: kv[1])
         print("  (%d,%d,%d,%d) x%d auto=%.0f best=%s %.0f" % (s["M"], s["N"], s["K"], s["ks"], s["launches"], s["us"].get("auto", 0), b[0], b[1]), flush=True)
-    json.dump({"rows": rows, "per_forward": True, "shapes": shapes}, open("gpurun_out/fwd_tune_b%d.json" % rows, "w"), indent=1)
+    json.dump({"rows": rows, "per_forward": True, "shapes": shapes}, open("gpurun_out/fwd_tune_b%d%s.json" % (rows, "bwd" if BWD else ""), "w"), indent=1)
