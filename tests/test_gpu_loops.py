@@ -208,6 +208,60 @@ def test_local_blend_substruct_words_against_reference_golden(small64):
     assert c1.cur_step == steps and c1.local_blend.counter == steps
     r, frac = masked_rel(out1[1], got[1], tol_frac=0.002)
     assert frac <= 0.002 and r < 2e-3, (r, frac)
+    # the same through objects of the REFERENCE's shape (class names, attributes and protocol of models/p2p/attention_control.py, written
+    # here because the reference tree is not on this box): registered by a function of the reference's shape through the attention-site
+    # markers, the controller is read into a kernel descriptor off its attributes (LocalBlend and substruct words included) and its
+    # step_callback -- which would read the never-filled attention_store -- is pointed at the native blend
+    c2 = ctrl(True)
+
+    class LocalBlend:                           # attributes of attention_control.py:123-147
+        def __init__(self, lb):
+            self.alpha_layers, self.substruct_layers = lb.alpha_layers.cuda(), lb.substruct_layers.cuda()
+            self.start_blend, self.th, self.counter = lb.start_blend, lb.th, 0
+
+        def __call__(self, x_t, attention_store):
+            raise AssertionError("the reference's LocalBlend.__call__ must not run: its maps live in the library")
+
+    class AttentionRefine:                      # attributes of attention_control.py:251-337
+        def __init__(self, c):
+            self.mapper, self.alphas = c.mapper.cuda(), c.alphas.cuda()
+            self.cross_replace_alpha, self.num_self_replace = c.cross_replace_alpha.cuda(), c.num_self_replace
+            self.local_blend, self.cur_step, self.cur_att_layer, self.num_att_layers, self.attention_store = LocalBlend(c.local_blend), 0, 0, -1, {}
+
+        def between_steps(self):
+            pass
+
+        def step_callback(self, x_t):           # :253-256
+            return self.local_blend(x_t, self.attention_store)
+
+        def __call__(self, attn, is_cross, place_in_unet):
+            raise AssertionError("a controller with a kernel descriptor is never called back")
+
+    foreign = AttentionRefine(c2)
+
+    def register(model, controller):            # models/p2p/attention_control.py:12-81, condensed
+        def ca_forward(self, place_in_unet):
+            def forward(x, context=None, mask=None, **kwargs):
+                return controller(x, context is not None, place_in_unet)
+            return forward
+        n = 0
+        for name, net in model.unet.named_children():
+            for place in ("down", "up", "mid"):
+                if place in name:
+                    for site in net.children():
+                        site.forward = ca_forward(site, place)
+                        n += 1
+        controller.num_att_layers = n
+    register(pipe, foreign)
+    try:
+        assert isinstance(pipe.unet.controller, ac.ForeignControllerAdapter) and pipe.unet.controller.wrapped is foreign
+        assert foreign.num_att_layers == pipe.unet.num_att_layers
+        lat = torch.cat((x_stars[-1], x_stars[-1])).cuda()
+        out2 = _level1_loop(pipe, foreign, lat, lambda i: ctx.cuda(), 7.5, [n for n in nl[:, 0]], 1).cpu()
+    finally:
+        pipe.unet.set_controller(None)
+    assert foreign.cur_step == steps and foreign.local_blend.counter == steps
+    assert torch.equal(out2, out1)              # the same descriptor, the same kernels
 
 
 @pytest.mark.parametrize("name", ["refine", "replace"])
