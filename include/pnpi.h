@@ -275,7 +275,7 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
  * one-launch GroupNorm below this many rows; "igemm_dma" (1) LDS-DMA kernel family; "igemm_table" (1) measured tile table before the
  * cost model; "igemm_wide" (1) 128x320 / 128x256 tiles; "igemm_deep_rings" (1) deeper LDS rings on sparse launches; "igemm_vt_lds" (1)
  * transposed V^T epilogue through LDS; "igemm_bias_init" (1) bias as the accumulators' initial value; "igemm_sched" (0 / 1) hand-scheduled GEMM main loop (fragment
- * reads behind counted lgkmcnt waits, DMA instructions between the MFMAs); "attn_bwd_flash" (1) self-attention backward without the score matrices in memory (0: materialised everywhere); "attn_vt_perm" (1) V^T of the 4096-token self-attention sites stored in the permuted key order the LDS-DMA flash kernel reads with one
+ * reads behind counted lgkmcnt waits, DMA instructions between the MFMAs); "attn_bwd_flash" (1) attention backward of the null-text path without the score matrices in memory (0: materialised everywhere, 2: flash form with the two-pass dQ even where the forward left its log-sum-exp, 3: flash form for self-attention only); "attn_vt_perm" (1) V^T of the 4096-token self-attention sites stored in the permuted key order the LDS-DMA flash kernel reads with one
  * 16-byte fragment load ("op_attention_vt_perm": pnpi_op_attention is handed such a V^T -- kernel tests); "igemm_res_late" (0) residual
  * added in the store loop; "igemm_force_cfg" (-1) / "igemm_force_split" (0) one tile id / split-K for every launch (sweeps);
  * "igemm_table_near" (1) nearest-row-count table entry for untabled M; "igemm_v128", "igemm_v64", "igemm_v256", "igemm_v320",
