@@ -290,6 +290,27 @@ def main():
                          "unet_backward_rows": cn["unet_backward_rows"], "executed_tflop_per_image": ex / 1e12, "executed_tflops_per_gpu": ex / dtn / 1e12,
                          "note": "null-text-inversion+p2p, %d DDIM steps x 10 Adam iterations (synthetic weights never reach the early-stop "
                                  "threshold); executed FLOPs = 2*M*N*K of every GEMM / attention launch incl. the backward pass" % args.ddim_steps}
+            # the same method with four images in flight (P2PEditor.edit_stream_in_flight: image i on library context i % 4, each with its
+            # own HIP stream and worker thread): the null-text path is one-row launch chains almost throughout, independent chains fill the gaps
+            try:
+                kw2 = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6)
+                its = lambda lo, n: [(synthetic_image(7000 + lo + j), PROMPT_SRC, PROMPT_TGT, (("cat",), ("dog",)), {"words": ("dog",), "values": (2,)})
+                                     for j in range(n)]
+                nf = 4
+                for _ in ed_nt.edit_stream_in_flight("null-text-inversion+p2p", its(0, nf), n_flight=nf, **kw2):     # builds and warms the contexts
+                    pass
+                barrier()
+                t2 = time.perf_counter()
+                n2 = 2 * nf
+                for _ in ed_nt.edit_stream_in_flight("null-text-inversion+p2p", its(nf, n2), n_flight=nf, **kw2):
+                    pass
+                barrier()
+                dt2 = time.perf_counter() - t2
+                null_text["in_flight"] = {"n_flight": nf, "value": n2 / dt2, "unit": "images/s", "s_per_image": dt2 / n2, "images": n2,
+                                          "note": "same edits, image i on library context i % n_flight (own HIP stream and worker thread each)"}
+                ed_nt.close_peers()
+            except Exception as e:
+                null_text["in_flight"] = {"error": "%s: %s" % (type(e).__name__, e)}
         except Exception as e:   # an extra must never take the headline line down
             null_text = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -344,6 +365,34 @@ def main():
                                  "(the first image's inversion is not overlapped and is inside the timed region)"}
         except Exception as e:   # an extra must never take the headline line down
             pipelined = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # extra (never `value`): the headline method with three images in flight (P2PEditor.edit_stream_in_flight: image i on library context
+    # i % 3 of this GPU, own HIP stream and worker thread each; same kernels, same panels) -- the sweep mode of run_editing_p2p.py
+    in_flight = None
+    if args.schedule == "lockstep" and not args.no_extras:
+        try:
+            nf = 3
+            mk = lambda lo, n: [(synthetic_image(12000 + 1000 * rank + lo + j), PROMPT_SRC, PROMPT_TGT, (("cat",), ("dog",)), {"words": ("dog",), "values": (2,)})
+                                for j in range(n)]
+            kwf = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6)
+            for _ in editor.edit_stream_in_flight("directinversion+p2p", mk(0, nf), n_flight=nf, **kwf):
+                pass
+            barrier()
+            tf = time.perf_counter()
+            n_if = 4 * nf
+            for _ in editor.edit_stream_in_flight("directinversion+p2p", mk(nf, n_if), n_flight=nf, **kwf):
+                pass
+            barrier()
+            dtf = time.perf_counter() - tf
+            if dist is not None:
+                tt = torch.tensor([dtf], device="cuda", dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtf = float(tt.item())
+            in_flight = {"n_flight": nf, "value": n_if * world / dtf, "unit": "images/s", "images": n_if, "ms_per_image": dtf / n_if * 1e3,
+                         "note": "faithful schedule per image; image i on library context i % n_flight (own HIP stream and worker thread each)"}
+            editor.close_peers()
+        except Exception as e:   # an extra must never take the headline line down
+            in_flight = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         # HBM-side traffic of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of
@@ -404,6 +453,8 @@ def main():
             out["batched"] = batched
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if in_flight is not None:
+            out["in_flight"] = in_flight
         if null_text is not None:
             out["null_text"] = null_text
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, see cpu_baseline)

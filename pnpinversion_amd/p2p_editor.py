@@ -373,6 +373,75 @@ class P2PEditor:
             self._inverter = p
         return self._inverter
 
+    def _peer_editors(self, n):
+        """n further P2PEditors, each on a full library context of its own (own HIP stream, a copy of the packed weight arena, the same
+        workspace sizes): `edit_stream_in_flight` spreads the images of a sweep over this editor and them."""
+        from .distributed import arena_tensor
+        from .pipeline import NativeTextEncoder
+        peers = self.__dict__.setdefault("_peers", [])
+        main = self.ldm_stable
+        while len(peers) < n:
+            torch.cuda.synchronize(main.device)
+            stream = torch.cuda.Stream(device=main.device)
+            with torch.cuda.device(main.device), torch.cuda.stream(stream):
+                native_text = isinstance(main.text_encoder, NativeTextEncoder)
+                # one image per context: 12 UNet rows (the lock-step loop) are the most any method string launches
+                p = NativePipeline(main.engine.cfg, device=main.device, max_unet_rows=min(main.engine.max_unet_rows, 12),
+                                   max_vae_images=min(main.engine.max_vae_images, 2), tokenizer=main.tokenizer,
+                                   text_encoder="native" if native_text else main.text_encoder)
+                arena_tensor(p.engine).copy_(arena_tensor(main.engine))
+                stream.synchronize()
+                p.engine.mark_all_loaded()
+            peer = P2PEditor(self.method_list, self.device, num_ddim_steps=self.num_ddim_steps, pipeline=p)
+            peers.append((peer, stream))
+        for peer, _ in peers:
+            peer.lockstep, peer.schedule = self.lockstep, self.schedule
+        return peers[:n]
+
+    def close_peers(self):
+        """Free the extra library contexts `edit_stream_in_flight` created."""
+        for peer, _ in self.__dict__.pop("_peers", []):
+            peer.ldm_stable.engine.close()
+
+    def edit_stream_in_flight(self, edit_method, items, n_flight=2, **kw):
+        """ANY method string over a sequence of images with n_flight images in flight: image i runs on context i % n_flight (this
+        editor's, or one of n_flight - 1 further contexts with their own HIP streams), each context fed by its own worker thread.  The
+        one-row launch chains of an edit (DDIM inversion; every forward and reverse walk of the null-text optimisation) keep a fraction of
+        the chip busy between dependent launches -- independent chains fill the gaps.  Same kernels on the same inputs as
+        `editor(edit_method, ...)` image by image -> identical panels; only sweep throughput changes (the reference's sweep visits images
+        one by one, run_editing_p2p.py:239-300).  items: iterable of (image_path | array, prompt_src, prompt_tar[, blend_word[,
+        eq_params]]); kw: the other keyword arguments of __call__.  Generator of panels, in order."""
+        from concurrent.futures import ThreadPoolExecutor
+        from contextlib import ExitStack
+        items = list(items)
+        if n_flight < 1:
+            raise ValueError("n_flight must be >= 1")
+        lanes = [(self, None)] + self._peer_editors(n_flight - 1)
+        dev = self.ldm_stable.device
+
+        def run(editor, stream, it):
+            extra = {}
+            if len(it) > 3:
+                extra["blend_word"] = it[3]
+            if len(it) > 4:
+                extra["eq_params"] = it[4]
+            with torch.no_grad(), torch.cuda.device(dev):
+                if stream is None:
+                    return editor(edit_method, it[0], it[1], it[2], **extra, **kw)
+                with torch.cuda.stream(stream):
+                    out = editor(edit_method, it[0], it[1], it[2], **extra, **kw)
+                    stream.synchronize()
+                    return out
+
+        with ExitStack() as stack:       # one single-worker queue per context: never two edits on one context
+            pools = [stack.enter_context(ThreadPoolExecutor(max_workers=1)) for _ in lanes]
+            futs = [pools[i % n_flight].submit(run, lanes[i % n_flight][0], lanes[i % n_flight][1], it) for i, it in enumerate(items)]
+            for f in futs:
+                yield f.result()
+
+    def edit_stream_two_in_flight(self, edit_method, items, **kw):
+        return self.edit_stream_in_flight(edit_method, items, n_flight=2, **kw)
+
     def edit_stream_directinversion(self, items, guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
                                     is_replace_controller=False):
         """`directinversion+p2p` over a sequence of images with stage overlap: while image i runs its 50 twelve-row lock-step steps on

@@ -264,6 +264,33 @@ def test_local_blend_substruct_words_against_reference_golden(small64):
     assert torch.equal(out2, out1)              # the same descriptor, the same kernels
 
 
+@pytest.mark.parametrize("method", ["null-text-inversion+p2p", "directinversion+p2p"])
+def test_two_images_in_flight_give_the_sequential_panels(small64, method):
+    """P2PEditor.edit_stream_in_flight: image i on library context i % n_flight, each context with its own HIP stream and worker thread --
+    the same kernels on the same inputs as the image-by-image calls, so the 4-panel images are identical (n_flight 2 and 3)."""
+    steps = 2
+    ed = P2PEditor([method], "cuda", num_ddim_steps=steps, pipeline=small64)
+    from PIL import Image
+    base = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    rng = np.random.RandomState(5)
+    imgs = [np.clip(base.astype(np.int32) + rng.randint(-20, 21, base.shape), 0, 255).astype(np.uint8) for _ in range(3)]
+    prompts = [("a cat sitting on a wooden chair", "a dog sitting on a wooden chair", (("cat",), ("dog",)), {"words": ("dog",), "values": (2,)}),
+               ("a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate", None, None),
+               ("a cat sitting on a wooden chair", "a dog sitting on a wooden chair", None, None)]
+    kw = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6)
+    seq = [np.array(ed(method, im, ps, pt, blend_word=bw, eq_params=eq, **kw)) for im, (ps, pt, bw, eq) in zip(imgs, prompts)]
+    items = [(im, ps, pt, bw, eq) for im, (ps, pt, bw, eq) in zip(imgs, prompts)]
+    try:
+        got = [np.array(p) for p in ed.edit_stream_in_flight(method, items, n_flight=2, **kw)]
+        got3 = [np.array(p) for p in ed.edit_stream_in_flight(method, items, n_flight=3, **kw)]
+    finally:
+        ed.close_peers()
+    assert len(got) == 3 and all(np.array_equal(a, b) for a, b in zip(got3, got))
+    for a, b in zip(got, seq):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert not np.array_equal(seq[0], seq[2])
+
+
 @pytest.mark.parametrize("name", ["refine", "replace"])
 def test_pruned_schedule_matches_faithful(small64, name):
     """SURVEY.md Note D: the pruned-equivalent schedule (3 rows per step: the source latent assigned from the inversion trajectory)
