@@ -947,16 +947,15 @@ int launch_attn_bwd_reduce(const AttnBwdP& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-static int g_abf_prefetch = 1;     // PNPI_ABF_PREFETCH=0: never the register-prefetch variant (A/B)
 template <int DP, int LT>
 static int launch_abf(const AttnBwdP& p, int mode, hipStream_t st) {
   if (p.nsplit < 1 || (p.nsplit > 1 && (mode == 0 || !p.part))) return -3;
   const int T = ((p.nb + 127) >> 7) * p.heads * p.nsplit;
   const dim3 grid((unsigned)(((T + 7) / 8) * 8));
-  static const bool pf_on = !(getenv("PNPI_ABF_PREFETCH") && atoi(getenv("PNPI_ABF_PREFETCH")) == 0);
+  static const bool pf_on = !(getenv("PNPI_ABF_PREFETCH") && atoi(getenv("PNPI_ABF_PREFETCH")) == 0);   // PNPI_ABF_PREFETCH=0: never the register-prefetch variant (A/B)
   if constexpr (DP == 64 || DP == 96) {
     // many loop tiles per workgroup and at most ~one workgroup per CU: prefetch the next tile into registers
-    if (pf_on && g_abf_prefetch && p.nl >= 8 * LT && T <= 512) {
+    if (pf_on && p.nl >= 8 * LT && T <= 512) {
       if (mode == 0) attn_bwd_flash_kernel<DP, LT, 0, true><<<grid, 256, 0, st>>>(p);
       else if (mode == 1) attn_bwd_flash_kernel<DP, LT, 1, true><<<grid, 256, 0, st>>>(p);
       else attn_bwd_flash_kernel<DP, LT, 2, true><<<grid, 256, 0, st>>>(p);
