@@ -26,6 +26,9 @@ Fixtures (the reference has no tests / golden vectors of its own for this path -
                        128 x 128 crop (TINY16 weights, AttentionRefine): per-step embeddings on every / the first unconditional row, l0 proximal step
   null_latent_tiny.npz DirectInversion.invert_null_latent (ablation_null-latent-inversion+p2p) on a 128 x 128 crop, TINY16 weights: inversion
                        latents, per-step latent offsets, every Adam iteration's loss
+  e2e_null_text_sd1.npz / e2e_masactrl_sd1.npz / unet_ctxgrad_sd1.npz  BASELINE configs 4 and 5 at the FULL SD-1.x width (weight seed 0): the
+                       reference's P2PEditor("null-text-inversion+p2p") with 2 steps x 10 Adam iterations, its MasaCtrlEditor with 4 steps (mutual
+                       self-attention from step 1), and torch.autograd through its UNet for d eps / d context (one row)
   clip_tiny/sd1.npz    transformers CLIPTextModel last_hidden_state (the reference's model.text_encoder), seeded weights
   method_dispatch.json P2PEditor.__call__'s routing of its 39 method strings (handler + method-specific arguments)
 """
@@ -115,6 +118,33 @@ def model_goldens():
                             mean=mean.numpy(), dec=dec.numpy(), seed=np.int64(seed))
         del vae
         print("model goldens", name, "%.1fs" % (time.time() - t0))
+
+
+def unet_ctxgrad_sd1():
+    """d(eps . d_eps) / d(context) through the reference's own full-width UNet2DConditionModel with its hooked attention forward
+    (torch.autograd, one row): what models/p2p/inversion.py:196-234 differentiates in every Adam iteration.  Pins pnpi_unet_context_grad
+    (activation tape, dgrad through the forward GEMM family, flash attention backward) at the benchmarked width."""
+    ref_shim.install()
+    from models.p2p.attention_control import register_attention_control
+    cfg, seed, t = SD1, 0, 481
+    t0 = time.time()
+    usd = weights.unet_state_dict(cfg, seed)
+    g = torch.Generator().manual_seed(300 + seed)
+    lat = torch.randn(1, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g)
+    ctx = weights.synth_context(cfg, 1, seed=400 + seed).half().float()        # fp16-representable: the same values on both sides
+    d_eps = torch.randn(1, cfg.in_channels, cfg.sample_size, cfg.sample_size, generator=g)
+    unet = ref_shim.build_unet(cfg, usd)
+    h = ref_shim._Holder()
+    h.unet = unet
+    register_attention_control(h, None)
+    for q in unet.parameters():
+        q.requires_grad_(False)
+    cr = ctx.clone().requires_grad_(True)
+    eps = unet(lat, torch.tensor(t), encoder_hidden_states=cr)["sample"]
+    eps.backward(d_eps)
+    np.savez_compressed(os.path.join(OUT, "unet_ctxgrad_sd1.npz"), latents=lat.numpy(), context=ctx.numpy().astype(np.float16), d_eps=d_eps.numpy(),
+                        t=np.int64(t), seed=np.int64(seed), eps=eps.detach().numpy(), d_context=cr.grad.numpy())
+    print("unet_ctxgrad_sd1 %.1fs |d_context| = %.3e" % (time.time() - t0, float(cr.grad.norm())))
 
 
 def e2e(name, is_replace, blend, steps=2, cfg=SMALL64, seed=2, pair=None, keep_every=1):
@@ -454,15 +484,15 @@ def proximal_recon(steps=4):
     np.savez_compressed(os.path.join(OUT, "e2e_proximal_recon.npz"), **out)
 
 
-def null_text(steps=3):
-    """P2PEditor("null-text-inversion+p2p") of the reference (models/p2p_editor.py:199-259): NullInversion.invert = ddim_inversion +
+def null_text(steps=3, cfg=SMALL64, seed=2, name="e2e_null_text"):
+    """cfg=SD1 (name e2e_null_text_sd1, 2 steps x 10 Adam iterations, weight seed 0): BASELINE config 4 at the benchmarked width.
+    P2PEditor("null-text-inversion+p2p") of the reference (models/p2p_editor.py:199-259): NullInversion.invert = ddim_inversion +
     null_optimization (10 Adam iterations per step through the UNet w.r.t. the 77 x D unconditional embedding, inversion.py:196-234),
     then p2p_guidance_forward twice with the per-step embeddings.  Same image / prompts / weights / controller as e2e_refine.
     The native path does not build this method yet (it needs the UNet backward pass); the fixture pins the ORACLE's restatement
     (oracle/p2p_oracle.py: null_optimization) so that the device implementation has a checker waiting."""
     ref_shim.install()
-    cfg = SMALL64
-    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    usd, vsd = weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed)
     ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
     src, tgt, w0, w1 = PROMPT_PAIRS[0]
     from PIL import Image
@@ -500,10 +530,10 @@ def null_text(steps=3):
     finally:
         pe.p2p_guidance_forward, inv.NullInversion.invert, inv.nnf.mse_loss = orig_fwd, orig_inv, orig_mse
     assert len(calls) == 2
-    np.savez_compressed(os.path.join(OUT, "e2e_null_text.npz"), x_stars=stages["x_stars"], uncond_embeddings=stages["uncond"],
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_stars=stages["x_stars"], uncond_embeddings=stages["uncond"],
                         context=stages["context"], losses=np.array(losses, dtype=np.float64), reconstruct_latent=calls[0],
                         edited_latents=calls[1], edited_image_small=np.array(panel)[::4, 3 * 512::4], steps=np.int64(steps), src=src, tgt=tgt,
-                        blend=np.array([w0, w1]))
+                        blend=np.array([w0, w1]), weight_seed=np.int64(seed))
     print("null_text %.1fs, %d inner iterations, loss %.3e -> %.3e" % (time.time() - t0, len(losses), losses[0], losses[-1]))
 
 
@@ -595,13 +625,13 @@ def null_text_family(steps=3):
     print("null_text_family %.1fs" % (time.time() - t0), {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
-def masactrl(steps=6, start_step=2, start_layer=10):
-    """run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
+def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e2e_masactrl"):
+    """cfg=SD1 (name e2e_masactrl_sd1, 4 steps, mutual self-attention from step 1, weight seed 0): BASELINE config 5 at the benchmarked width.
+    run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
     editor relies on that default for its second call (run_editing_masactrl.py:118-121); the default is set to `steps` here."""
     import inspect
-    cfg = SMALL64
-    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    usd, vsd = weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed)
     ed = ref_shim.build_masactrl_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
     from models.masactrl.diffuser_utils import MasaCtrlPipeline
     import models.p2p.inversion as inv
@@ -614,7 +644,8 @@ def masactrl(steps=6, start_step=2, start_layer=10):
     fn.__defaults__ = tuple(d)
     src, tgt = PROMPT_PAIRS[0][0], PROMPT_PAIRS[0][1]
     img_path = os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")
-    out = {"steps": np.int64(steps), "start_step": np.int64(start_step), "start_layer": np.int64(start_layer), "src": src, "tgt": tgt}
+    out = {"steps": np.int64(steps), "start_step": np.int64(start_step), "start_layer": np.int64(start_layer), "src": src, "tgt": tgt,
+           "weight_seed": np.int64(seed)}
     for m in ("directinversion+masactrl", "ddim+masactrl"):
         t0 = time.time()
         decoded, stages = [], {}
@@ -657,7 +688,7 @@ def masactrl(steps=6, start_step=2, start_layer=10):
         out[m + "/recon_image_small"] = p[::4, 1024:1536:4]
         out[m + "/edited_image_small"] = p[::4, 1536::4]
         print("masactrl", m, "%.1fs" % (time.time() - t0), {k: v.shape for k, v in out.items() if k.startswith(m + "/")})
-    np.savez_compressed(os.path.join(OUT, "e2e_masactrl.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
 if __name__ == "__main__":
@@ -694,6 +725,14 @@ if __name__ == "__main__":
         proximal_recon()
     if "null_text" in which or not sys.argv[1:]:
         null_text()
+    if "unet_ctxgrad_sd1" in which:
+        unet_ctxgrad_sd1()
+    if "null_text_sd1" in which:
+        # BASELINE config 4 at the benchmarked width: 2 steps x 10 Adam iterations through the full-width UNet (about 10 CPU-minutes)
+        null_text(steps=2, cfg=SD1, seed=0, name="e2e_null_text_sd1")
+    if "masactrl_sd1" in which:
+        # BASELINE config 5 at the benchmarked width: 4 steps, mutual self-attention from step 1 in transformer blocks 10..15
+        masactrl(steps=4, start_step=1, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1")
     if "null_latent" in which or not sys.argv[1:]:
         null_latent()
     if "null_text_family" in which or not sys.argv[1:]:

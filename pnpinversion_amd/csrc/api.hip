@@ -1778,7 +1778,8 @@ int pnpi_profile_end(pnpi_ctx* c, pnpi_kernel_stats* out) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         char kn[96] = "-";     // the kernel template a rocprofv3 kernel trace shows for this launch
-        if (r.geom[0]) snprintf(kn, sizeof kn, "igemm_dma_kernel<%d %d %d %d %d %d %d>", r.geom[0], r.geom[1], r.geom[2], r.geom[3], r.geom[4], r.geom[5], r.geom[6]);
+        if (r.geom[0] && r.geom[6] == -1) snprintf(kn, sizeof kn, "igemm_pp_kernel<%d %d %d %d %d>", r.geom[0], r.geom[1], r.geom[2], r.geom[3], r.geom[4]);
+        else if (r.geom[0]) snprintf(kn, sizeof kn, "igemm_dma_kernel<%d %d %d %d %d %d %d>", r.geom[0], r.geom[1], r.geom[2], r.geom[3], r.geom[4], r.geom[5], r.geom[6]);
         else if (r.cfg >= 0) snprintf(kn, sizeof kn, "igemm_kernel");
         fprintf(f, "%d,%d,%d,%d,%d,%.3f,%.0f,%d,%d,%s,%.0f\n", r.cls, r.M, r.N, r.K, r.ksize, ms * 1e3, r.flops, r.cfg, r.split, kn, r.bytes);
       }

@@ -15,6 +15,7 @@
 
 #include "ops.h"
 #include "igemm_dma.inc"
+#include "igemm_pp.inc"
 
 static constexpr int BK = 64;
 static constexpr int LDS_LD = BK + 8;  // halfs
@@ -311,6 +312,27 @@ static int launch_dma(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t
   return 0;
 }
 
+// The 8-wave ping-pong kernel (igemm_pp.inc): one workgroup per CU, same tile-order / grid conventions as launch_dma.
+template <int BM, int BN, int MI0, int NI0, int ABL = 0>
+static int launch_pp(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t* zero_page) {
+  using GEO = PpGeom<BM, BN, MI0, NI0>;
+  g_last_geom[0] = BM; g_last_geom[1] = BN; g_last_geom[2] = MI0; g_last_geom[3] = NI0; g_last_geom[4] = ABL; g_last_geom[5] = 0; g_last_geom[6] = -1;   // [6] = -1: igemm_pp_kernel
+  GemmP p = p_in;
+  p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
+  {
+    const double bytes_a = 2.0 * p.B * p.H * p.W * (p.C1 + p.C2), bytes_w = 2.0 * (double)p.N * p.K;
+    p.tile_order = (bytes_a + 8 * bytes_w <= 8 * bytes_a + bytes_w) ? 0 : 1;
+    if (g_tile_order >= 0) p.tile_order = g_tile_order;
+  }
+  const int total = (int)(grid.x * grid.y * grid.z);
+  grid = dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
+  constexpr int lds = GEO::LDS;
+  static DeviceOnce attr_once;
+  if (int r = once_per_device(attr_once, [&]() { return (int)hipFuncSetAttribute((const void*)igemm_pp_kernel<BM, BN, MI0, NI0, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); })) return r;
+  igemm_pp_kernel<BM, BN, MI0, NI0, ABL><<<grid, GEO::NT, lds, st>>>(p, zero_page);
+  return 0;
+}
+
 // Deterministic split-K combine: fixed slab order, then the common epilogue.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmP p) {
   const int groups_per_row = (p.N + 3) / 4;
@@ -376,6 +398,7 @@ static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
 static int g_bias_init = 1;     // 0: bias added in the epilogue (ablation)
+static int g_varpp = 0;         // tuning "igemm_vpp": ablations of the ping-pong kernel (1 = no MFMAs, 2 = no DMA; both produce garbage)
 static int g_sched = 0;         // tuning "igemm_sched" = 1: the hand-scheduled main loop (igemm_dma_kernel<..., ABL = 4>) for the one-k-group tile configurations
 static int g_force_split = 0;   // > 0 with igemm_force_cfg: split-K of every auto-configured launch (in-forward tuning sweeps)
 static thread_local int g_last_cfg = -1, g_last_split = 1;   // per thread: two contexts may launch from two threads   // what the most recent launch_igemm used (profiling dumps)
@@ -387,7 +410,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_sched", &g_sched}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_sched", &g_sched}, {"igemm_vpp", &g_varpp}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -477,7 +500,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   if (cfg < 0 && g_use_table && dma_ok) {
     if (const TileEntry* pe = tile_table_lookup(p.M, p.N, p.K, p.ksize, nullptr)) {
         const TileEntry& e = *pe;
-        const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12) ? 320 : ((e.cfg == 5 || e.cfg == 7 || e.cfg == 15) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
+        const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12 || e.cfg == 17) ? 320 : ((e.cfg == 5 || e.cfg == 7 || e.cfg == 15 || e.cfg == 16) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
         const bool split_ok = e.split == 1 || (!p.geglu && ws && (size_t)e.split * p.M * p.N * sizeof(float) <= ws_bytes);
         const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
         if (split_ok && vt_ok && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14)) { cfg = e.cfg; split = e.split; }
@@ -529,13 +552,25 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     if (split > nchunks) split = nchunks;
     if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu || cfg == 3) split = 1;
   }
-  const bool c64 = cfg == 1 || cfg == 8 || cfg == 11 || cfg == 12, c256m = cfg == 3 || cfg == 6 || cfg == 7;
-  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12 || cfg == 15) ? 9 : (c64 ? 1 : 0));
+  if (cfg == 16 || cfg == 17) {
+    // the ping-pong kernel has no scalar epilogue: a launch either takes the LDS epilogue (whole tiles plain or transposed, 16-byte rows,
+    // 16-byte aligned bias) or writes split-K slabs; anything else goes to the 128 x 128 kernel
+    const int bn_pp = cfg == 17 ? 320 : 256;
+    const bool vt_none_ = p.vt_col0 >= p.N;
+    const bool vt_lds_ = !vt_none_ && p.outT && !p.vt_f32 && p.vt_col0 % bn_pp == 0 && p.rows_per_batch % 8 == 0 && p.vt_ld % 8 == 0 && p.M % 8 == 0 && !p.res &&
+                         !p.geglu && g_vt_lds;
+    const bool epi_ok = (vt_none_ || vt_lds_) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) &&
+                        (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.vt_perm16 || p.rows_per_batch % 16 == 0);
+    if (!dma_ok || (split == 1 && !epi_ok) || (split > 1 && p.N % 4 != 0)) cfg = 0;
+  }
+  const bool c64 = cfg == 1 || cfg == 8 || cfg == 11 || cfg == 12, c256m = cfg == 3 || cfg == 6 || cfg == 7 || cfg == 16;
+  const bool cpp = cfg == 16 || cfg == 17;      // the 8-wave ping-pong kernel: 16 = 256 x 256, 17 = 192 x 320
+  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12 || cfg >= 15) ? 9 : (c64 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   g_last_cfg = cfg; g_last_split = split;
   for (int i = 0; i < 7; ++i) g_last_geom[i] = 0;
-  const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12) ? 320 : ((cfg == 5 || cfg == 7 || cfg == 15) ? 256 : (c64 ? 64 : 128));
+  const int bn_sel = (cfg == 4 || cfg == 6 || cfg == 12 || cfg == 17) ? 320 : ((cfg == 5 || cfg == 7 || cfg == 15 || cfg == 16) ? 256 : (c64 ? 64 : 128));
   const bool vt_none = p.vt_col0 >= p.N;
   // transposed (V^T) columns through the LDS epilogue too, when whole tiles are either plain or transposed and 8-token runs stay
   // inside one batch item
@@ -544,13 +579,13 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   p.epi_lds = (vt_none || vt_lds) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) && split == 1;
   if (vt_lds) p.stats = nullptr;
   p.res_late = g_res_late;
-  p.bias_init = (dma_ok && split == 1 && p.bias && p.alpha == 1.f && p.N % 4 == 0 && ((uintptr_t)p.bias & 15) == 0 && g_bias_init) ? 1 : 0;
+  p.bias_init = (dma_ok && split == 1 && p.bias && p.alpha == 1.f && p.N % 4 == 0 && ((uintptr_t)p.bias & 15) == 0 && g_bias_init && !cpp) ? 1 : 0;
   if (p.vt_perm16 && (p.rows_per_batch % 16 != 0 || p.vt_f32)) return -9;   // permuted V^T: whole 16-token groups, fp16
   if (p.geglu && !(p.epi_lds && dma_ok && p.N % 64 == 0)) return -7;   // GEGLU exists only in the LDS epilogue
   if (!(p.epi_lds && dma_ok && !p.geglu)) p.stats = nullptr;       // statistics come only from the DMA kernel's LDS epilogue
-  const int bm = c256m ? 256 : (c64 ? 64 : 128);
+  const int bm = cfg == 17 ? 192 : (c256m ? 256 : (c64 ? 64 : 128));
   const int bn = bn_sel;
-  if (stats_tile_rows) *stats_tile_rows = p.stats ? bm : 0;
+  if (stats_tile_rows) *stats_tile_rows = p.stats ? (cpp ? 64 : bm) : 0;     // the ping-pong kernel writes its partials per 64-row sub-block
   p.slab = ws;
   if (p.nbatch > 1) {
     if (split != 1 || p.bias || p.res || p.stats || p.geglu || p.x2) return -8;     // batched launches: plain products only
@@ -597,6 +632,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     r = launch_dma<128, 128, 32, 3, 2, 0, 2>(p, grid, st, g_zero_page);    // 8 waves: 2 k-groups, 96 KB
   } else if (cfg == 10) {
     r = launch_dma<128, 128, 64, 2, 2, 0, 2>(p, grid, st, g_zero_page);    // 8 waves: 2 k-groups, 128-byte rows, 128 KB
+  } else if (cfg == 16) {
+    r = g_varpp == 1 ? launch_pp<256, 256, 2, 4, 1>(p, grid, st, g_zero_page) : g_varpp == 2 ? launch_pp<256, 256, 2, 4, 2>(p, grid, st, g_zero_page) : launch_pp<256, 256, 2, 4>(p, grid, st, g_zero_page);
+  } else if (cfg == 17) {
+    r = g_varpp == 1 ? launch_pp<192, 320, 1, 4, 1>(p, grid, st, g_zero_page) : g_varpp == 2 ? launch_pp<192, 320, 1, 4, 2>(p, grid, st, g_zero_page) : launch_pp<192, 320, 1, 4>(p, grid, st, g_zero_page);
   } else if (cfg == 6) {
     r = launch_dma<256, 320, 64, 2, 4>(p, grid, st, g_zero_page);
   } else if (cfg == 7) {

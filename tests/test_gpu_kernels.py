@@ -41,6 +41,10 @@ def h16(*shape, scale=1.0, seed=0):
     (768, 1280, 1280, 9, 0), (200, 130, 96, 9, 0), (512, 256, 4096, 10, 2), (128, 128, 64, 10, 0),   # 128x128 tile, 2 k-groups
     (1000, 640, 640, 12, 0), (100, 300, 128, 12, 0), (512, 320, 2048, 12, 2), (700, 384, 320, 13, 0),  # 64x320 tile; 128x128 two-stage
     (700, 384, 320, 14, 0), (512, 256, 4096, 14, 3), (1000, 768, 320, 15, 0), (77, 520, 192, 15, 0),   # 128-byte-row variants of 128x128 / 128x256
+    # 8-wave ping-pong kernel (igemm_pp.inc): 16 = 256x256, 17 = 192x320; K-tile counts 1, 2, 3 (prologue / drain paths), ragged M / N, split-K
+    (256, 256, 64, 16, 0), (256, 256, 128, 16, 0), (1000, 640, 640, 16, 0), (300, 328, 128, 16, 0), (700, 512, 256, 16, 0), (1000, 1280, 960, 16, 2),
+    (4096, 1536, 320, 16, 0), (384, 640, 192, 17, 0), (1000, 640, 640, 17, 0), (130, 328, 64, 17, 0), (192, 320, 2880, 17, 0), (4096, 320, 320, 17, 0),
+    (512, 320, 2048, 17, 4), (768, 1280, 11520, 17, 16), (3072, 1280, 1280, 17, 0),
 ])
 def test_gemm(ctx, M, N, K, cfg, split):
     a = h16(M, K, seed=1)
@@ -75,7 +79,8 @@ def test_gemm_wide_tile_variants(ctx, key, val, cfg):
 
 
 @pytest.mark.parametrize("cfg,N,v320", [(0, 320, 0), (1, 192, 0), (4, 320, 0), (4, 640, 1), (5, 512, 0), (5, 256, 1), (6, 320, 0), (7, 256, 0),
-                                        (8, 192, 1), (9, 256, 1), (12, 320, 1), (13, 256, 1), (14, 256, 1), (15, 512, 1)])
+                                        (8, 192, 1), (9, 256, 1), (12, 320, 1), (13, 256, 1), (14, 256, 1), (15, 512, 1), (16, 256, 1), (16, 512, 1),
+                                        (17, 320, 1), (17, 640, 1)])
 def test_conv_epilogue_groupnorm_statistics(ctx, cfg, N, v320):
     """The per-(m-tile, channel) sum / sum-of-squares partials a conv epilogue hands to the consumer GroupNorm: fp32 sums of the
     STORED fp16 values, every tile configuration (incl. the two-pass epilogue of the 2-stage wide tiles), ragged last m-tile."""
@@ -98,7 +103,7 @@ def test_conv_epilogue_groupnorm_statistics(ctx, cfg, N, v320):
         for key in (b"igemm_v320", b"igemm_v256n"):
             ctx.lib.pnpi_set_tuning(key, 1)
     tr = rows.value
-    assert tr == {1: 64, 8: 64, 11: 64, 12: 64, 6: 256, 7: 256}.get(cfg, 128)
+    assert tr == {1: 64, 8: 64, 11: 64, 12: 64, 6: 256, 7: 256, 16: 64, 17: 64}.get(cfg, 128)    # the ping-pong kernel: 64-row sub-blocks
     ref = F.conv2d(x.float(), w.float(), bias, padding=1)
     assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-3
     o = out.reshape(M, N).float()
@@ -136,7 +141,8 @@ def test_gemm_transposed_region(ctx):
 
 
 @pytest.mark.parametrize("cfg,col0,N,T,vt_lds", [(8, 128, 192, 64, 1), (9, 256, 384, 256, 1), (0, 256, 384, 64, 1), (1, 128, 192, 256, 1), (5, 512, 768, 1024, 1), (4, 640, 960, 64, 1),
-                                                  (0, 256, 384, 64, 0), (4, 512, 768, 256, 1)])
+                                                  (0, 256, 384, 64, 0), (4, 512, 768, 256, 1), (16, 512, 768, 1024, 1), (16, 256, 512, 64, 1), (17, 640, 960, 64, 1),
+                                                  (17, 640, 960, 4096, 1)])
 def test_gemm_transposed_columns_through_lds_epilogue(ctx, cfg, col0, N, T, vt_lds):
     """Fused q|k|v projection: columns >= col0 leave TRANSPOSED per batch item (V^T for the attention kernel).  With tile-aligned
     col0 the LDS epilogue stages those tiles transposed and stores 8-token runs (tokens per item below, equal to and above the tile
@@ -191,6 +197,14 @@ def pack_w(w):  # [N, C, kh, kw] -> [N, kh*kw*C] tap-major
     (3, 64, 64, 16, 320, 1, 1, 0, 6, 0),      # 256x320 tile (8 waves), concat, ragged M
     (2, 128, 0, 16, 256, 1, 1, 0, 7, 0),      # 256x256 tile (8 waves)
     (2, 64, 0, 8, 64, 1, 1, 1, 3, 0),         # 256x128 tile with the folded upsample
+    (3, 64, 64, 16, 320, 1, 1, 0, 17, 0),     # ping-pong 192x320, concat (source switch inside the k-walk), ragged M
+    (1, 320, 0, 32, 320, 1, 1, 0, 17, 0),     # ping-pong 192x320, SD shape (45 K-tiles)
+    (2, 128, 0, 16, 256, 1, 1, 0, 16, 0),     # ping-pong 256x256
+    (2, 64, 0, 8, 64, 1, 1, 1, 16, 0),        # ping-pong 256x256 with the folded upsample
+    (2, 128, 0, 16, 256, 2, 1, 0, 16, 0),     # ping-pong 256x256, stride 2
+    (2, 64, 0, 16, 64, 2, 0, 0, 17, 0),       # ping-pong 192x320, VAE downsample (pad (0,1,0,1))
+    (4, 1280, 0, 8, 320, 1, 1, 0, 17, 6),     # ping-pong 192x320, deep K, split-K
+    (3, 128, 64, 16, 640, 1, 1, 0, 17, 2),    # ping-pong 192x320, concat + split-K (a split starts inside the second source)
 ])
 def test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
     W = H
@@ -283,7 +297,7 @@ def test_geglu(ctx):
     assert rel_err(out, a * F.gelu(g)) < 2e-3
 
 
-@pytest.mark.parametrize("force", [-1, 0, 1, 4, 5, 6, 8, 9, 12, 13, 14, 15])
+@pytest.mark.parametrize("force", [-1, 0, 1, 4, 5, 6, 8, 9, 12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("M,K,I", [(4096, 320, 1280), (1024, 640, 2560), (200, 1280, 5120), (64, 64, 64)])
 def test_gemm_fused_geglu(ctx, M, K, I, force):
     """GEGLU.forward (my_diffusers/models/attention.py:331-333): proj -> chunk -> x * gelu(gate), fused into the GEMM epilogue

@@ -11,10 +11,10 @@ from pnpinversion_amd import weights
 from pnpinversion_amd.config import SD1
 from pnpinversion_amd.engine import NativeEngine
 rows_list = [int(a) for a in sys.argv[1:]] or [12, 1]
-NAME = {0: "128", 1: "64", 3: "256m", 4: "320", 5: "256n", 6: "256x320", 7: "256x256", 8: "64k4", 9: "128k2", 10: "128k2b", 11: "64k2", 12: "64x320", 13: "128n2", 14: "128b64", 15: "256nb64"}
-SINGLE = [0, 1, 3, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8]
-SPLIT_CFGS = [0, 1, 4, 5, 11, 14]
-SPLITS = [2, 3, 4, 6, 8, 12]
+NAME = {0: "128", 1: "64", 3: "256m", 4: "320", 5: "256n", 6: "256x320", 7: "256x256", 8: "64k4", 9: "128k2", 10: "128k2b", 11: "64k2", 12: "64x320", 13: "128n2", 14: "128b64", 15: "256nb64", 16: "pp256", 17: "pp320"}
+SINGLE = [0, 1, 3, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8, 16, 17]
+SPLIT_CFGS = [0, 1, 4, 5, 11, 14, 16, 17]
+SPLITS = [2, 3, 4, 6, 8, 12, 16]
 eng = NativeEngine(SD1, max_unet_rows=max(rows_list + [4]), max_vae_images=1)
 eng.load_state_dict({k: v.cuda() for k, v in weights.unet_state_dict(SD1, 0).items()}, {k: v.cuda() for k, v in weights.vae_state_dict(SD1, 0).items()})
 lib = eng.lib
