@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
+#include <memory>
+#include <string>
 
 #include "model.h"
 
@@ -2414,30 +2417,42 @@ int pnpi_op_softmax_rows(pnpi_ctx* c, void* x, int M, int N, int ld) {
 // ---- differentiable UNet forward (null-text path groundwork)
 static int tape_ensure(pnpi_ctx* c) {
   if (c->tape) return 0;
-  Tape* T = new Tape();
   const pnpi_model_config& g = c->cfg;
-  T->garena.cap = (size_t)2560 << 20;                    // gradients + dgrad scratch of one UNet row (SD-1.x: ~1.1 GB)
-  CKH(hipMalloc((void**)&T->garena.base, T->garena.cap));
-  CKH(hipMalloc((void**)&T->d_ctx, (size_t)g.ctx_len * g.cross_dim * sizeof(float)));
-  c->tape = T;
   // The activation arenas were sized at create for max_unet_rows rows of the plain forward (block temporaries released in stack order).
   // A recording forward of ONE row keeps every temporary: measure it with a dry run and grow the arenas if that is more (set-up time
-  // only -- nothing is allocated in the optimisation loop).
+  // only -- nothing is allocated in the optimisation loop).  New buffers are allocated BEFORE the old ones are freed and the context's
+  // state changes only after every allocation has succeeded: a failed hipMalloc leaves the context as it was (and without a tape).
+  std::unique_ptr<Tape> T(new Tape());
+  CKH(hipStreamSynchronize(c->st));
+  size_t pp, tp;
   {
-    CKH(hipStreamSynchronize(c->st));
     const Bump sp = c->persist, stmp = c->temp;
+    Tape* const prev = c->tape;
     c->persist = Bump(); c->temp = Bump();
+    c->tape = T.get();
     c->dry = true; T->rec = true;
     const bool kv = c->tkv.use; c->tkv.use = false;
     const int r = unet_fwd(c, nullptr, 1, 0, nullptr, false, 0, nullptr);
     c->dry = false; T->rec = false; c->tkv.use = kv;
-    const size_t pp = align_up(c->persist.peak + (1 << 20), 4096), tp = align_up(c->temp.peak + (1 << 20), 4096);
-    c->persist = sp; c->temp = stmp;
+    pp = align_up(c->persist.peak + (1 << 20), 4096); tp = align_up(c->temp.peak + (1 << 20), 4096);
+    c->persist = sp; c->temp = stmp; c->tape = prev;
     if (r) return r;
-    if (pp > c->persist.cap) { CKH(hipFree(c->persist.base)); c->persist.base = nullptr; CKH(hipMalloc((void**)&c->persist.base, pp)); c->persist.cap = pp; }
-    if (tp > c->temp.cap) { CKH(hipFree(c->temp.base)); c->temp.base = nullptr; CKH(hipMalloc((void**)&c->temp.base, tp)); c->temp.cap = tp; }
-    c->persist.reset(); c->temp.reset(); c->persist.overflow = false; c->temp.overflow = false;
   }
+  // gradients + dgrad scratch of one UNet row: about 2.8x the recorded activations at SD-1.x width (1.1 of 0.4 GB); 6x with a 64 MB floor
+  const size_t gcap = align_up(std::max((size_t)64 << 20, 6 * (pp + tp)), 4096);
+  char *gbase = nullptr, *nper = nullptr, *ntmp = nullptr;
+  float* dctx = nullptr;
+  auto undo = [&]() { if (gbase) (void)hipFree(gbase); if (nper) (void)hipFree(nper); if (ntmp) (void)hipFree(ntmp); if (dctx) (void)hipFree(dctx); };
+  hipError_t e = hipMalloc((void**)&gbase, gcap);
+  if (e == hipSuccess) e = hipMalloc((void**)&dctx, (size_t)g.ctx_len * g.cross_dim * sizeof(float));
+  if (e == hipSuccess && pp > c->persist.cap) e = hipMalloc((void**)&nper, pp);
+  if (e == hipSuccess && tp > c->temp.cap) e = hipMalloc((void**)&ntmp, tp);
+  if (e != hipSuccess) { undo(); const std::string msg = std::string("null-text tape: ") + hipGetErrorString(e); return fail(c, PNPI_EHIP, msg.c_str()); }
+  if (nper) { (void)hipFree(c->persist.base); c->persist.base = nper; c->persist.cap = pp; }
+  if (ntmp) { (void)hipFree(c->temp.base); c->temp.base = ntmp; c->temp.cap = tp; }
+  c->persist.reset(); c->temp.reset(); c->persist.overflow = false; c->temp.overflow = false;
+  T->garena.base = gbase; T->garena.cap = gcap; T->d_ctx = dctx;
+  c->tape = T.release();
   return 0;
 }
 // eps = UNet(latents, t, context) for ONE row, and d_context = (d loss / d eps)^T (d eps / d context) for the given d loss / d eps

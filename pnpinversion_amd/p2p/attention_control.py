@@ -287,6 +287,8 @@ def is_callback_controller(controller):
     materialise-and-call-back path of pnpi_set_attention_callback (slow, exact semantics)."""
     if controller is None or not callable(controller):
         return False
+    if isinstance(controller, AttentionControlEdit):        # native edit classes: the flag (set by hand) is ignored, see force_callback
+        return False
     return getattr(controller, "_pnpi_force_callback", False) or not hasattr(controller, "tables")
 
 
@@ -382,7 +384,12 @@ class _NoEditAdapter(ForeignControllerAdapter):
 
 
 def force_callback(controller):
-    """Mark a controller so that it always runs through the call-back path (e.g. an AttentionStore whose stored maps are wanted)."""
+    """Mark a controller so that it always runs through the call-back path (e.g. an AttentionStore whose stored maps are wanted).
+    This module's own AttentionReplace / Refine / Reweight carry their edit as kernel tables, not as a Python `forward`: forcing them
+    through the call-back path would silently run a plain, unedited forward, so that is an error."""
+    if isinstance(controller, AttentionControlEdit):
+        raise TypeError("force_callback: %s edits through the kernel descriptor (tables()) and has no Python forward to call back into; "
+                        "force an AttentionStore or a controller object that implements forward()" % type(controller).__name__)
     controller._pnpi_force_callback = True
     return controller
 

@@ -412,7 +412,6 @@ class P2PEditor:
         one by one, run_editing_p2p.py:239-300).  items: iterable of (image_path | array, prompt_src, prompt_tar[, blend_word[,
         eq_params]]); kw: the other keyword arguments of __call__.  Generator of panels, in order."""
         from concurrent.futures import ThreadPoolExecutor
-        from contextlib import ExitStack
         items = list(items)
         if n_flight < 1:
             raise ValueError("n_flight must be >= 1")
@@ -433,11 +432,30 @@ class P2PEditor:
                     stream.synchronize()
                     return out
 
-        with ExitStack() as stack:       # one single-worker queue per context: never two edits on one context
-            pools = [stack.enter_context(ThreadPoolExecutor(max_workers=1)) for _ in lanes]
-            futs = [pools[i % n_flight].submit(run, lanes[i % n_flight][0], lanes[i % n_flight][1], it) for i, it in enumerate(items)]
-            for f in futs:
-                yield f.result()
+        # One single-worker queue per context (never two edits on one context), fed through a BOUNDED window: at most 2 * n_flight images
+        # are submitted ahead of the in-order consumer, each future is dropped once its panel has been handed over, and a failing image
+        # (or a consumer that stops early) cancels what has not started -- the reference's sweep also stops at the failing image.
+        from collections import deque
+        pools = [ThreadPoolExecutor(max_workers=1) for _ in lanes]
+        window, nxt = deque(), 0
+
+        def top_up():
+            nonlocal nxt
+            while nxt < len(items) and len(window) < 2 * n_flight:
+                lane = nxt % n_flight
+                window.append(pools[lane].submit(run, lanes[lane][0], lanes[lane][1], items[nxt]))
+                nxt += 1
+
+        try:
+            top_up()
+            while window:
+                out = window.popleft().result()
+                top_up()
+                yield out
+        finally:
+            window.clear()
+            for pool in pools:
+                pool.shutdown(wait=True, cancel_futures=True)
 
     def edit_stream_two_in_flight(self, edit_method, items, **kw):
         return self.edit_stream_in_flight(edit_method, items, n_flight=2, **kw)

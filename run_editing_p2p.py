@@ -112,7 +112,7 @@ def main(argv=None):
                 continue
             todo.append((src, tgt, image_path, blended, out_path))
         nb = args.batch_size if method in BATCHED_METHODS else 1
-        if args.images_in_flight > 1 and nb == 1:
+        if args.images_in_flight > 1 and nb == 1 and len(todo) >= 2:      # nothing / one image to edit: no extra contexts
             setup_seed()
             stream_items = [(c[2], c[0], c[1], ((c[3][0],), (c[3][1],)) if c[3] else None,
                              {"words": (c[3][1],), "values": (2,)} if c[3] else None) for c in todo]
@@ -158,6 +158,8 @@ def main(argv=None):
                 os.makedirs(os.path.dirname(c[4]), exist_ok=True)
                 panel.save(c[4])
                 print("finish")
+    if hasattr(editor, "close_peers"):
+        editor.close_peers()             # the extra library contexts of the in-flight sweep
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
