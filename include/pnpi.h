@@ -100,6 +100,11 @@ typedef struct {
                                       becomes mask & ~mask_sub, mask_sub = the same maps weighted by these rows, NOT max-pooled, thresholded
                                       at lb_threshold_sub                                    attention_control.py:97-106,114-116,134-143 */
   float lb_threshold_sub;          /* th[1] = 0.3 */
+  /* kind 2 with explicit lists (MutualSelfAttentionControl(layer_idx=, step_idx=), masactrl.py:24-37: membership tests at :61).  Both
+   * optional; when given they REPLACE the corresponding window above. */
+  unsigned masa_layer_mask;        /* bit b set: transformer block b (execution order 0..15) is in layer_idx; 0 = the start_layer window */
+  int masa_n_steps;                /* length of masa_step_on_host; 0 = the start_step window */
+  const unsigned char* masa_step_on_host;   /* [masa_n_steps]: 1 where the denoising step is in step_idx (steps past the end: off) */
 } pnpi_ctrl_desc;
 
 /* Reconstruction guidance of the proximal-guidance loop (models/p2p/proximal_guidance_forward.py:48-51,60-72 with

@@ -691,6 +691,39 @@ def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def masactrl_lists(steps=6, layer_idx=(10, 12, 15), step_idx=(1, 3, 4)):
+    """MutualSelfAttentionControl(layer_idx=..., step_idx=...) (models/masactrl/masactrl.py:14-39: arbitrary lists instead of the
+    [start_step, total) x [start_layer, 16) windows; no shipped script passes them): the reference's MasaCtrlPipeline.__call__ on SMALL64
+    from the inverted latent of e2e_masactrl.npz's ddim+masactrl run, with the reference's own controller object built by hand."""
+    cfg, seed = SMALL64, 2
+    usd, vsd = weights.unet_state_dict(cfg, seed), weights.vae_state_dict(cfg, seed)
+    ed = ref_shim.build_masactrl_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    from models.masactrl.masactrl import MutualSelfAttentionControl
+    from models.masactrl.masactrl_utils import regiter_attention_editor_diffusers
+    g = np.load(os.path.join(OUT, "e2e_masactrl.npz"))
+    assert int(g["steps"]) == steps
+    x_t = torch.from_numpy(g["ddim+masactrl/x_stars"][-1])
+    tgt = str(g["tgt"])
+    decoded = []
+    orig_l2i = ed.model.latent2image
+
+    def l2i_spy(latents, return_type="np"):
+        decoded.append(latents.clone().numpy())
+        return orig_l2i(latents, return_type=return_type)
+
+    ed.model.latent2image = l2i_spy
+    try:
+        with ref_shim.cuda_to_cpu(), torch.no_grad():
+            editor = MutualSelfAttentionControl(layer_idx=list(layer_idx), step_idx=list(step_idx), total_steps=steps)
+            regiter_attention_editor_diffusers(ed.model, editor)
+            ed.model(["", tgt], latents=x_t.expand(2, -1, -1, -1), num_inference_steps=steps, guidance_scale=7.5)
+    finally:
+        ed.model.latent2image = orig_l2i
+    np.savez_compressed(os.path.join(OUT, "masactrl_lists.npz"), x_t=x_t.numpy(), latents=decoded[-1], layer_idx=np.array(layer_idx, np.int64),
+                        step_idx=np.array(step_idx, np.int64), steps=np.int64(steps), tgt=tgt)
+    print("masactrl_lists", decoded[-1].shape)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(int(os.environ.get("PNPI_GOLDEN_THREADS", os.cpu_count())))
@@ -733,6 +766,8 @@ if __name__ == "__main__":
     if "masactrl_sd1" in which:
         # BASELINE config 5 at the benchmarked width: 4 steps, mutual self-attention from step 1 in transformer blocks 10..15
         masactrl(steps=4, start_step=1, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1")
+    if "masactrl_lists" in which:
+        masactrl_lists()
     if "null_latent" in which or not sys.argv[1:]:
         null_latent()
     if "null_text_family" in which or not sys.argv[1:]:

@@ -35,6 +35,7 @@ class CtrlDesc(C.Structure):
         ("lb_alpha_host", C.POINTER(C.c_float)),
         ("masa_start_step", C.c_int), ("masa_start_layer", C.c_int),
         ("lb_sub_alpha_host", C.POINTER(C.c_float)), ("lb_threshold_sub", C.c_float),
+        ("masa_layer_mask", C.c_uint), ("masa_n_steps", C.c_int), ("masa_step_on_host", C.POINTER(C.c_ubyte)),
     ]
 
 

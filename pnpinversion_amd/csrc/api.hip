@@ -557,7 +557,9 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
     AttnP a; a.q = qk; a.ldq = 2 * hd; a.q_off = 0; a.k = qk; a.ldk = 2 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv; a.vt_perm = vperm;
     a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
-    const bool masa = use_ctrl && cd.masa_any && cur_step >= cd.masa_start_step && block_index >= cd.masa_start_layer;
+    const bool masa_step = cd.masa_step_list ? (cur_step >= 0 && cur_step < (int)cd.masa_step_on.size() && cd.masa_step_on[cur_step]) : cur_step >= cd.masa_start_step;
+    const bool masa_layer = cd.masa_layer_mask ? ((cd.masa_layer_mask >> block_index) & 1u) != 0 && block_index < 31 : block_index >= cd.masa_start_layer;
+    const bool masa = use_ctrl && cd.masa_any && masa_step && masa_layer;
     a.rows = rep ? cd.rows_rep : (masa ? cd.rows_masa : cd.rows_id); a.nrows = B;
     c->ctr.executed_attn_flops += 4.0 * B * t.heads * (double)N * N * t.Dp;
     if (c->attn_cb && !c->dry) {
@@ -1411,9 +1413,14 @@ static int setup_ctrl(pnpi_ctx* c, const pnpi_ctrl_desc* cds, int nimg, int rows
     for (int i = 0; i < nimg; ++i) {
       if (cds[i].kind != 2) continue;
       if (rpi != 4) return fail(c, PNPI_EINVAL, "MasaCtrl controllers need the 4-row layout");
-      if (cd.masa_any && (cd.masa_start_step != cds[i].masa_start_step || cd.masa_start_layer != cds[i].masa_start_layer))
-        return fail(c, PNPI_EINVAL, "all MasaCtrl controllers of one batch must share start_step / start_layer");
+      std::vector<unsigned char> step_on;
+      const bool step_list = cds[i].masa_n_steps > 0 && cds[i].masa_step_on_host;
+      if (step_list) step_on.assign(cds[i].masa_step_on_host, cds[i].masa_step_on_host + cds[i].masa_n_steps);
+      if (cd.masa_any && (cd.masa_start_step != cds[i].masa_start_step || cd.masa_start_layer != cds[i].masa_start_layer ||
+                          cd.masa_layer_mask != cds[i].masa_layer_mask || cd.masa_step_list != step_list || cd.masa_step_on != step_on))
+        return fail(c, PNPI_EINVAL, "all MasaCtrl controllers of one batch must share their step / layer windows (or lists)");
       cd.masa_any = true; cd.masa_start_step = cds[i].masa_start_step; cd.masa_start_layer = cds[i].masa_start_layer;
+      cd.masa_layer_mask = cds[i].masa_layer_mask; cd.masa_step_list = step_list; cd.masa_step_on = step_on;
       for (int half = 0; half < 2; ++half) {
         const int src = i * 4 + 2 * half, tgt = src + 1;
         masa[tgt * 4 + 2] = src; masa[tgt * 4 + 3] = src;

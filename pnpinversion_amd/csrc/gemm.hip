@@ -383,7 +383,7 @@ void gemm_defaults(GemmP& p) {
   p.w = nullptr; p.ldw = 0; p.M = 0; p.N = 0; p.K = 0; p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.alpha = 1.f;
   p.out = nullptr; p.ldo = 0; p.outT = nullptr; p.vt_col0 = 1 << 30; p.vt_ld = 0; p.vt_f32 = 0; p.rows_per_batch = 1; p.vt_perm16 = 0;
   p.slab = nullptr; p.splitk = 1; p.kchunks_per_split = 0; p.geglu = 0; p.epi_lds = 0; p.stats = nullptr; p.res_late = 0; p.bias_init = 0;
-  p.nbatch = 1; p.sx1 = 0; p.sw = 0; p.sout = 0; p.soutT = 0;
+  p.k_order = 0; p.nbatch = 1; p.sx1 = 0; p.sw = 0; p.sout = 0; p.soutT = 0;
 }
 
 static constexpr size_t lds_bytes(int BM, int BN) { return (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(half_t); }
@@ -398,6 +398,8 @@ static int g_res_late = 0;     // tuning "igemm_res_late" = 1: residual added in
 static int g_vt_lds = 1;       // tuning "igemm_vt_lds" = 0: transposed columns through the scalar epilogue (A/B)
 static int g_deep_rings = 1;   // tuning "igemm_deep_rings" = 0: shallow rings whatever the occupancy (A/B)
 static int g_bias_init = 1;     // 0: bias added in the epilogue (ablation)
+static int g_pp_only_n = 0, g_pp_only_k = 0, g_pp_only_m = 0;   // tuning "igemm_pp_only_{m,n,k}" > 0: table entries of the ping-pong kernel apply only to launches with that M / N / K (bisection of a wrong layer)
+static int g_tapin = 0;         // tuning "igemm_tapin" = 1: the ping-pong kernel walks 3 x 3 convolutions channel-slab-major (GemmP::k_order)
 static int g_varpp = 0;         // tuning "igemm_vpp": ablations of the ping-pong kernel (1 = no MFMAs, 2 = no DMA; both produce garbage)
 static int g_sched = 0;         // tuning "igemm_sched" = 1: the hand-scheduled main loop (igemm_dma_kernel<..., ABL = 4>) for the one-k-group tile configurations
 static int g_force_split = 0;   // > 0 with igemm_force_cfg: split-K of every auto-configured launch (in-forward tuning sweeps)
@@ -410,7 +412,7 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 // process-wide tuning knobs (A/B measurements inside one process, tests of the non-default variants); 0 on success
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
-                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_sched", &g_sched}, {"igemm_vpp", &g_varpp}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
+                                             {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_sched", &g_sched}, {"igemm_vpp", &g_varpp}, {"igemm_tapin", &g_tapin}, {"igemm_pp_only_n", &g_pp_only_n}, {"igemm_pp_only_k", &g_pp_only_k}, {"igemm_pp_only_m", &g_pp_only_m}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;
@@ -503,7 +505,9 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
         const int ebn = (e.cfg == 4 || e.cfg == 6 || e.cfg == 12 || e.cfg == 17) ? 320 : ((e.cfg == 5 || e.cfg == 7 || e.cfg == 15 || e.cfg == 16) ? 256 : ((e.cfg == 1 || e.cfg == 8 || e.cfg == 11) ? 64 : 128));
         const bool split_ok = e.split == 1 || (!p.geglu && ws && (size_t)e.split * p.M * p.N * sizeof(float) <= ws_bytes);
         const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
-        if (split_ok && vt_ok && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14)) { cfg = e.cfg; split = e.split; }
+        const bool pp_masked = (e.cfg == 16 || e.cfg == 17) && ((g_pp_only_n > 0 && p.N != g_pp_only_n) || (g_pp_only_k > 0 && p.K != g_pp_only_k) || (g_pp_only_m > 0 && p.M != g_pp_only_m) ||
+                                                                 g_pp_only_n < 0);
+        if (split_ok && vt_ok && !pp_masked && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14)) { cfg = e.cfg; split = e.split; }
     }
   }
   if (cfg < 0) {
@@ -632,10 +636,17 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     r = launch_dma<128, 128, 32, 3, 2, 0, 2>(p, grid, st, g_zero_page);    // 8 waves: 2 k-groups, 96 KB
   } else if (cfg == 10) {
     r = launch_dma<128, 128, 64, 2, 2, 0, 2>(p, grid, st, g_zero_page);    // 8 waves: 2 k-groups, 128-byte rows, 128 KB
-  } else if (cfg == 16) {
-    r = g_varpp == 1 ? launch_pp<256, 256, 2, 4, 1>(p, grid, st, g_zero_page) : g_varpp == 2 ? launch_pp<256, 256, 2, 4, 2>(p, grid, st, g_zero_page) : launch_pp<256, 256, 2, 4>(p, grid, st, g_zero_page);
-  } else if (cfg == 17) {
-    r = g_varpp == 1 ? launch_pp<192, 320, 1, 4, 1>(p, grid, st, g_zero_page) : g_varpp == 2 ? launch_pp<192, 320, 1, 4, 2>(p, grid, st, g_zero_page) : launch_pp<192, 320, 1, 4>(p, grid, st, g_zero_page);
+  } else if (cfg == 16 || cfg == 17) {
+    p.k_order = (g_tapin && p.ksize == 3) ? 1 : 0;
+#define LPP(...) (cfg == 16 ? launch_pp<256, 256, 2, 4, __VA_ARGS__>(p, grid, st, g_zero_page) : launch_pp<192, 320, 1, 4, __VA_ARGS__>(p, grid, st, g_zero_page))
+    switch (g_varpp) {
+      case 1: r = LPP(1); break;     // ablations: no MFMAs
+      case 2: r = LPP(2); break;     // no DMA
+      case 3: r = LPP(3); break;     // DMA only
+      case 4: r = LPP(4); break;     // MFMAs only
+      default: r = LPP(0); break;
+    }
+#undef LPP
   } else if (cfg == 6) {
     r = launch_dma<256, 320, 64, 2, 4>(p, grid, st, g_zero_page);
   } else if (cfg == 7) {

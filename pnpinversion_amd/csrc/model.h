@@ -143,6 +143,9 @@ struct CtrlDev {
   int* rows_masa = nullptr;       // [rows][4] MasaCtrl: target rows read K, V of the source row of their CFG half
   bool masa_any = false;
   int masa_start_step = 0, masa_start_layer = 0;
+  unsigned masa_layer_mask = 0;                     // bit 31: a layer_idx list was given (bits 0..15 = its blocks); 0 = the start_layer window
+  std::vector<unsigned char> masa_step_on;          // step_idx list as a per-step flag array; empty + !masa_step_list = the start_step window
+  bool masa_step_list = false;
   int n_plain = 0;
   int* pairs = nullptr;           // [npairs][2]
   half_t* mmatT = nullptr;        // [npairs][96][96]

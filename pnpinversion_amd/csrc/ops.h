@@ -29,6 +29,7 @@ struct GemmP {
   int epi_lds;    // set by launch_igemm: coalesced LDS-staged epilogue is applicable
   int bias_init;  // set by launch_igemm: the LDS-DMA kernel starts its accumulators at the bias (alpha == 1, no split-K) and its epilogue adds none
   int res_late;   // set by launch_igemm: the LDS epilogue adds the residual in its store loop instead of staging it
+  int k_order;    // set by launch_igemm for the ping-pong kernel: 1 = 3 x 3 convolutions walk k channel-slab-major (nine taps per 64-channel slab in a row)
   int gx, gy, gz, tile_order;   // set by the launcher: logical tile grid and XCD-aware traversal order (see igemm_dma_kernel)
   // nbatch > 1: the launch holds nbatch independent problems of the same shape (grid z = problem index; no split-K): problem z reads
   // x1 + z * sx1, w + z * sw and writes out + z * sout (elements) / outT + z * soutT (bytes).  The attention backward's per-head GEMMs.

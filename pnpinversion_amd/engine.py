@@ -56,13 +56,31 @@ class ControllerTables:
 class MasaCtrlTables:
     """MutualSelfAttentionControl (models/masactrl/masactrl.py:14-72) -> pnpi_ctrl_desc kind 2."""
 
-    def __init__(self, start_step=4, start_layer=10):
+    def __init__(self, start_step=4, start_layer=10, layer_idx=None, step_idx=None):
+        """layer_idx / step_idx: explicit lists (any subset of transformer blocks 0..15 / denoising steps); None = the window."""
         self.start_step, self.start_layer = int(start_step), int(start_layer)
+        self.layer_mask = 0
+        if layer_idx is not None:
+            for b in layer_idx:
+                if 0 <= int(b) < 32:                      # blocks past the UNet's 16 never match, as in the reference's `in` test
+                    self.layer_mask |= 1 << int(b)
+            self.layer_mask |= 1 << 31                    # "a list was given" (an empty list switches the control off everywhere)
+        self.step_on = None
+        if step_idx is not None:
+            n = max([int(x) for x in step_idx if int(x) >= 0], default=-1) + 1
+            self.step_on = (C.c_ubyte * max(n, 1))()
+            for x in step_idx:
+                if int(x) >= 0:
+                    self.step_on[int(x)] = 1
 
     def desc(self):
         d = _capi.CtrlDesc()
         d.kind = 2
         d.masa_start_step, d.masa_start_layer = self.start_step, self.start_layer
+        d.masa_layer_mask = self.layer_mask
+        if self.step_on is not None:
+            d.masa_n_steps = len(self.step_on)
+            d.masa_step_on_host = C.cast(self.step_on, C.POINTER(C.c_ubyte))
         return d
 
 

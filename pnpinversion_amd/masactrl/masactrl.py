@@ -1,6 +1,7 @@
 """MutualSelfAttentionControl with the constructor of models/masactrl/masactrl.py:14-39.  Semantics (:57-69): at denoising steps
 >= start_step and transformer blocks >= start_layer (execution order 0..15), every self-attention row of a CFG half reads the K
-and V of the half's FIRST row (the source image) -- in the kernel a row-indirection table of the flash-attention launch."""
+and V of the half's FIRST row (the source image) -- in the kernel a row-indirection table of the flash-attention launch.
+`layer_idx` / `step_idx` lists (any subsets) replace the windows, as in the reference."""
 from ..engine import MasaCtrlTables
 from .masactrl_utils import AttentionBase
 
@@ -16,8 +17,10 @@ class MutualSelfAttentionControl(AttentionBase):
         self.start_layer = start_layer
         self.layer_idx = layer_idx if layer_idx is not None else list(range(start_layer, self.total_layers))
         self.step_idx = step_idx if step_idx is not None else list(range(start_step, total_steps))
-        if self.layer_idx != list(range(start_layer, self.total_layers)) or self.step_idx != list(range(start_step, total_steps)):
-            raise NotImplementedError("the native path takes contiguous [start_step, total) x [start_layer, 16) windows only")
 
     def tables(self):
-        return MasaCtrlTables(self.start_step, self.start_layer)
+        # the reference tests membership (`cur_step not in self.step_idx`, `cur_att_layer // 2 not in self.layer_idx`, masactrl.py:61):
+        # the lists travel as a 16-bit block mask and a per-step byte array; the default windows keep their two integers
+        win_l = self.layer_idx == list(range(self.start_layer, self.total_layers))
+        win_s = self.step_idx == list(range(self.start_step, self.total_steps))
+        return MasaCtrlTables(self.start_step, self.start_layer, None if win_l else self.layer_idx, None if win_s else self.step_idx)

@@ -45,6 +45,7 @@ def h16(*shape, scale=1.0, seed=0):
     (256, 256, 64, 16, 0), (256, 256, 128, 16, 0), (1000, 640, 640, 16, 0), (300, 328, 128, 16, 0), (700, 512, 256, 16, 0), (1000, 1280, 960, 16, 2),
     (4096, 1536, 320, 16, 0), (384, 640, 192, 17, 0), (1000, 640, 640, 17, 0), (130, 328, 64, 17, 0), (192, 320, 2880, 17, 0), (4096, 320, 320, 17, 0),
     (512, 320, 2048, 17, 4), (768, 1280, 11520, 17, 16), (3072, 1280, 1280, 17, 0),
+    (40000, 320, 128, 17, 0), (33000, 256, 64, 16, 0),          # a linear layer is one image row of M pixels: M beyond 2^15
 ])
 def test_gemm(ctx, M, N, K, cfg, split):
     a = h16(M, K, seed=1)
@@ -233,6 +234,19 @@ def test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
     torch.cuda.synchronize()
     got = out.permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 2e-3, (rel_err(got, ref), max_err(got, ref))
+
+
+@pytest.mark.parametrize("B,C1,C2,H,N,stride,pad,ups,cfg,split", [
+    (3, 64, 64, 16, 320, 1, 1, 0, 17, 0), (1, 320, 0, 32, 320, 1, 1, 0, 17, 0), (2, 128, 0, 16, 256, 2, 1, 0, 16, 0), (2, 64, 0, 8, 64, 1, 1, 1, 16, 0),
+    (4, 1280, 0, 8, 320, 1, 1, 0, 17, 6), (3, 128, 64, 16, 640, 1, 1, 0, 17, 2)])
+def test_conv3x3_channel_slab_major_walk(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
+    """The ping-pong kernel's other k order (tuning igemm_tapin: the nine filter taps of a 64-channel slab in a row, GemmP::k_order): same
+    products, another summation order -- concat sources, stride 2, the folded upsample and split-K ranges of the permuted walk."""
+    assert ctx.lib.pnpi_set_tuning(b"igemm_tapin", 1) == 0
+    try:
+        test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split)
+    finally:
+        ctx.lib.pnpi_set_tuning(b"igemm_tapin", 0)
 
 
 def test_conv1x1_concat(ctx):

@@ -528,6 +528,46 @@ def test_masactrl_editor_against_reference_golden(method):
     pipe.engine.close()
 
 
+def test_masactrl_layer_and_step_lists_against_reference_golden():
+    """MutualSelfAttentionControl(layer_idx=[10, 12, 15], step_idx=[1, 3, 4]) (models/masactrl/masactrl.py:24-37,61: arbitrary lists, not
+    windows) as descriptor masks, against the reference's own MasaCtrlPipeline run with its own controller object
+    (tests/golden/masactrl_lists.npz, SMALL64, 6 steps); the lists that spell the default windows give the window result bit for bit."""
+    from pnpinversion_amd.masactrl.diffuser_utils import MasaCtrlPipeline
+    from pnpinversion_amd.masactrl.masactrl import MutualSelfAttentionControl
+    from pnpinversion_amd.masactrl.masactrl_utils import regiter_attention_editor_diffusers
+    g = np.load(os.path.join(GOLD, "masactrl_lists.npz"))
+    cfg, steps = SMALL64, int(g["steps"])
+    pipe = MasaCtrlPipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    x_t = torch.from_numpy(g["x_t"]).cuda()
+    tgt = str(g["tgt"])
+    got = {}
+    orig = pipe.latent2image
+
+    def spy(latents, return_type="np"):
+        got["lat"] = latents.detach().clone()
+        return orig(latents, return_type=return_type)
+
+    pipe.latent2image = spy
+
+    def run(**kw):
+        regiter_attention_editor_diffusers(pipe, MutualSelfAttentionControl(total_steps=steps, **kw))
+        pipe(["", tgt], latents=x_t.expand(2, -1, -1, -1), num_inference_steps=steps, guidance_scale=7.5)
+        return got["lat"].cpu()
+
+    lists = run(layer_idx=[int(x) for x in g["layer_idx"]], step_idx=[int(x) for x in g["step_idx"]])
+    ref = torch.from_numpy(g["latents"])
+    assert rel(lists, ref) < 2e-2, rel(lists, ref)
+    window = run(start_step=2, start_layer=10)
+    assert (window[1] - lists[1]).abs().mean().item() > 1e-3                   # the lists matter
+    assert torch.equal(window[0], lists[0])                                     # the source row never reads another row
+    same = run(start_step=2, start_layer=10, layer_idx=list(range(10, 16)), step_idx=list(range(2, steps)))
+    assert torch.equal(same, window)
+    off = run(layer_idx=[], step_idx=[0, 1])                                    # an empty layer list: no mutual attention anywhere
+    assert torch.equal(off[0], window[0]) and (off[1] - window[1]).abs().mean().item() > 1e-3
+    pipe.engine.close()
+
+
 def test_sweep_driver_cli(tmp_path, capsys):
     """run_editing_p2p.py end to end on a 3-image PIE-Bench-shaped data directory: output tree of the reference
     (output/<method>/annotation_images/...), --batch_size grouping, skip-if-exists resume (run_editing_p2p.py:239-300)."""

@@ -40,7 +40,7 @@ for (cin, hw, cout) in convs:
 cin, hw, cout = 320, 64, 320
 x = torch.randn(B, hw, hw, cin, device=DEV).half(); w = (torch.randn(cout, 9 * cin, device=DEV) / math.sqrt(9 * cin)).half()
 bias = torch.randn(cout, device=DEV); out = torch.empty(B, hw, hw, cout, device=DEV, dtype=torch.half)
-for vpp in (0, 1, 2):
+for vpp in (0, 1, 2, 3, 4):
     assert lib.pnpi_set_tuning(b"igemm_vpp", vpp) == 0
     for cfg in (16, 17):
         f = lambda: ctx.call("pnpi_op_conv", ptr(x), None, cin, 0, B, hw, hw, 3, 1, 1, 0, hw, hw, ptr(w), ptr(bias), None, cout, ptr(out), cfg, 0)
@@ -48,6 +48,18 @@ for vpp in (0, 1, 2):
         res.append({"op": "ablation", "vpp": vpp, "cfg": cfg, "us": t * 1e6, "tflops_equiv": 2.0 * B * hw * hw * cout * 9 * cin / t / 1e12})
         print(res[-1], flush=True)
 lib.pnpi_set_tuning(b"igemm_vpp", 0)
+# channel-slab-major k-walk of the 3 x 3 convolutions (tuning igemm_tapin) against the default tap-major one, in turn
+for (cin, hw, cout, cfg, split) in [(320, 64, 320, 17, 0), (960, 64, 320, 17, 0), (640, 32, 640, 17, 2), (1280, 16, 1280, 17, 4), (1280, 16, 1280, 16, 4), (2560, 16, 1280, 17, 4)]:
+    x = torch.randn(B, hw, hw, cin, device=DEV).half(); w = (torch.randn(cout, 9 * cin, device=DEV) / math.sqrt(9 * cin)).half()
+    bias = torch.randn(cout, device=DEV); out = torch.empty(B, hw, hw, cout, device=DEV, dtype=torch.half)
+    f = lambda: ctx.call("pnpi_op_conv", ptr(x), None, cin, 0, B, hw, hw, 3, 1, 1, 0, hw, hw, ptr(w), ptr(bias), None, cout, ptr(out), cfg, split)
+    for rnd in range(2):
+        for tapin in (0, 1):
+            assert lib.pnpi_set_tuning(b"igemm_tapin", tapin) == 0
+            t = timeit(f)
+            res.append({"op": "tapin", "cin": cin, "hw": hw, "cout": cout, "cfg": cfg, "split": split, "tapin": tapin, "us": t * 1e6, "tflops": 2.0 * B * hw * hw * cout * 9 * cin / t / 1e12})
+            print(res[-1], flush=True)
+lib.pnpi_set_tuning(b"igemm_tapin", 0)
 gemms = [(49152, 320, 2560, [(-1, 0), (13, 0), (16, 0), (17, 0)]), (49152, 320, 1536, [(-1, 0), (0, 0), (16, 0)]), (49152, 1280, 320, [(-1, 0), (14, 0), (17, 0)]),
          (49152, 320, 320, [(-1, 0), (0, 0), (17, 0)]), (12288, 640, 5120, [(-1, 0), (0, 0), (16, 0), (17, 0)]), (12288, 2560, 640, [(-1, 0), (14, 0), (17, 0), (17, 2)]),
          (12288, 640, 640, [(-1, 0), (14, 0), (17, 0)]), (3072, 1280, 10240, [(-1, 0), (14, 0), (16, 0), (17, 0)]), (3072, 5120, 1280, [(-1, 0), (17, 4), (17, 2)]),
