@@ -395,39 +395,52 @@ def main():
             in_flight = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
-        # HBM-side traffic of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of
-        # this same command, reduced by tools/pmc_summary.py (gfx950 correction applied there) and committed under profiles/.
+        # HBM-side traffic / MFMA busy of the dominant kernel per launch: FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES from separate
+        # rocprofv3 --pmc passes of THIS command with --ddim-steps 2 (tools/profile_round.sh: the counter service dies on the ~100 000
+        # launches of a full run; same kernels, same launch shapes, same 1 : 1 mix of one-row and twelve-row forwards), reduced by
+        # tools/pmc_summary.py and committed under profiles/ with the source hash of the kernels they were measured on.  A summary made
+        # from other kernel sources than the running tree is NOT reported (traffic: null + the reason).
+        from pnpinversion_amd.build import source_hash
         prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        pmc = next((os.path.join(prof, f) for f in ("round3_pmc_traffic_bench.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json")
-                    if os.path.exists(os.path.join(prof, f))), os.path.join(prof, "round2_pmc_traffic.json"))
-        if roofline is not None and os.path.exists(pmc):
-            tag = roofline["kernel"].replace(" ", "")           # igemm_dma_kernel<128,128,64,2,2,0,1>
-            for name, v in json.load(open(pmc))["kernels"].items():
-                if v.get("template") == tag:
-                    # counters were collected on the 12-row forwards of the lock-step loop (tools/profile_pmc.sh), so the algorithmic bytes
-                    # to compare with are those of the same launches, not this run's mix of 1-row and 12-row launches
-                    roofline["traffic"] = v["traffic_bytes"]
-                    roofline["traffic_alg_bytes_same_launches"] = v.get("alg_bytes_per_launch")
-                    roofline["traffic_over_alg"] = v.get("traffic_over_alg")
-                    if "mfma_util" in v:
-                        roofline["mfma_busy"] = v["mfma_util"]
-                    src_json = json.load(open(pmc))
-                    roofline["traffic_source"] = "profiles/%s: %s" % (os.path.basename(pmc), src_json.get(
-                        "source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of 12-row UNet forwards (tools/fwd_only.py), mean per launch of this kernel"))
-                    break
-        # the rocprofv3 --kernel-trace --stats average of the same kernel under `bench.py --no-extras` (committed summary): the HIP-event
-        # bracket above also carries the packet-processing gap in front of the kernel, which differs between boxes of the pool
-        stats_csv = os.path.join(prof, "round3_bench_noextras_kernel_stats.csv")
-        if roofline is not None and os.path.exists(stats_csv):
-            import csv
-            want = "igemm_dma_kernelI" + "E".join("Li%s" % a for a in roofline["kernel"].split("<")[1].rstrip(">").split(",")) + "EE"
-            for row in csv.DictReader(open(stats_csv)):
-                if want in row["Name"]:
-                    us = float(row["AverageNs"]) / 1e3
-                    roofline["rocprof"] = {"avg_launch_us": us, "calls": int(row["Calls"]),
-                                           "achieved": roofline["alg_flop_per_launch"] / us / 1e6, "frac": roofline["alg_flop_per_launch"] / us / 1e6 / MFMA_PEAK_TFLOPS,
-                                           "source": "profiles/round3_bench_noextras_kernel_stats.csv (committed; not this run)"}
-                    break
+        sha = source_hash()
+        if roofline is not None:
+            roofline["source_sha16"] = sha
+            tag = roofline["kernel"].replace(" ", "")           # igemm_pp_kernel<192,320,1,4,0>
+            pmc = os.path.join(prof, "round4_pmc_traffic_bench.json")
+            if not os.path.exists(pmc):
+                roofline["traffic_note"] = "no committed counter summary (profiles/round4_pmc_traffic_bench.json)"
+            else:
+                src_json = json.load(open(pmc))
+                if src_json.get("source_sha16") != sha:
+                    roofline["traffic_note"] = "profiles/round4_pmc_traffic_bench.json was measured on kernel sources %s, this tree is %s: not reported" % (
+                        src_json.get("source_sha16"), sha)
+                else:
+                    for name, v in src_json["kernels"].items():
+                        if v.get("template") == tag:
+                            roofline["traffic"] = v["traffic_bytes"]
+                            roofline["traffic_over_alg"] = v["traffic_bytes"] / roofline["alg_bytes_per_launch"]
+                            if "mfma_util" in v:
+                                roofline["mfma_busy"] = v["mfma_util"]
+                            roofline["traffic_source"] = "profiles/round4_pmc_traffic_bench.json (same kernel sources, %s): %s" % (sha, src_json.get("source"))
+                            break
+                    else:
+                        roofline["traffic_note"] = "the dominant kernel %s has no entry in profiles/round4_pmc_traffic_bench.json" % tag
+            # the rocprofv3 --kernel-trace --stats average of the same kernel under this command (committed summary + its source hash): the
+            # HIP-event bracket above also carries the packet-processing gap in front of the kernel, which differs between boxes of the pool
+            stats_csv, meta = os.path.join(prof, "round4_bench_kernel_stats.csv"), os.path.join(prof, "round4_bench_kernel_stats.meta.json")
+            if os.path.exists(stats_csv) and os.path.exists(meta) and json.load(open(meta)).get("source_sha16") == sha:
+                import csv
+                name, targs = tag.split("<")
+                want = "%d%sI" % (len(name), name) + "".join("Li%sE" % a for a in targs.rstrip(">").split(",")) + "E"
+                for row in csv.DictReader(open(stats_csv)):
+                    if want in row["Name"]:
+                        us = float(row["AverageNs"]) / 1e3
+                        roofline["rocprof"] = {"avg_launch_us": us, "calls": int(row["Calls"]),
+                                               "achieved": roofline["alg_flop_per_launch"] / us / 1e6,
+                                               "frac": roofline["alg_flop_per_launch"] / us / 1e6 / MFMA_PEAK_TFLOPS,
+                                               "source": "profiles/round4_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `bench.py --steps 2 "
+                                                         "--warmup 1 --no-extras --no-cpu-baseline` (faithful edits only; same kernel sources, %s)" % sha}
+                        break
         n_img = args.steps * world
         per_rank_flops = executed_flops(ctr)
         out = {

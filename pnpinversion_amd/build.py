@@ -20,6 +20,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", 
 EXTRA = {"step.hip": ["-ffp-contract=off"], "attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
+def source_hash():
+    """Identity of the kernels a libpnpi.so is built from: sha256 over the HIP sources, their includes and the per-file flags (16 hex
+    digits).  Committed profile summaries carry it; bench.py reports counters from a summary only if it matches the running tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    h.update(repr((FLAGS, sorted(EXTRA.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -73,4 +86,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    else:
+        build(force="--force" in sys.argv)
