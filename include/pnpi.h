@@ -136,6 +136,12 @@ typedef struct {
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
 /* replaces StableDiffusionPipeline.from_pretrained(...).to(device)             models/p2p_editor.py:23-25 */
 int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images);
+/* A further context on the SAME packed weights (same device, same model configuration): own stream, workspaces and caches, the
+ * parent's weight arena borrowed read-only instead of copied (several images in flight on one GPU: one 1.9 GB arena in the caches
+ * instead of N).  The parent must outlive the child; reloading the parent's weights while children exist is the caller's error
+ * (call pnpi_mark_all_loaded on each child afterwards); pnpi_load_weights on a child fails with PNPI_ESTATE.  There is no
+ * counterpart in the reference (one pipeline object per process, models/p2p_editor.py:18-25). */
+int pnpi_create_shared(pnpi_ctx** out, pnpi_ctx* parent, void* hip_stream, int max_unet_rows, int max_vae_images);
 void pnpi_destroy(pnpi_ctx* ctx);
 const char* pnpi_last_error(const pnpi_ctx* ctx);
 int pnpi_load_weights(pnpi_ctx* ctx, const pnpi_named_tensor* tensors, int n);

@@ -66,6 +66,7 @@ _fp = C.POINTER(C.c_float)
 SYMBOLS = {
     "pnpi_config_sd1": (None, [C.POINTER(ModelConfig)]),
     "pnpi_create": (_i, [C.POINTER(_vp), C.POINTER(ModelConfig), _i, _vp, _i, _i]),
+    "pnpi_create_shared": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i]),
     "pnpi_destroy": (None, [_vp]),
     "pnpi_last_error": (C.c_char_p, [_vp]),
     "pnpi_load_weights": (_i, [_vp, C.POINTER(NamedTensor), _i]),

@@ -1570,8 +1570,21 @@ static int validate_config(pnpi_ctx* c) {
 
 static int clip_fwd(pnpi_ctx* c, const int* ids, int n, float* out);
 
+static int create_impl(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images, pnpi_ctx* parent);
 int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images) {
   if (!out || !cfg) return PNPI_EINVAL;
+  return create_impl(out, cfg, device, hip_stream, max_unet_rows, max_vae_images, nullptr);
+}
+// A further context on the SAME packed weights: the new context borrows the parent's weight arena (read-only from here on) instead of
+// holding a copy -- several images in flight on one GPU (own stream, own workspaces, own caches) then share one 1.9 GB arena in the
+// Infinity Cache / L2 instead of competing with N copies of it.  The parent must outlive the child and its weights must not be
+// reloaded while children exist (a child refuses pnpi_load_weights).
+int pnpi_create_shared(pnpi_ctx** out, pnpi_ctx* parent, void* hip_stream, int max_unet_rows, int max_vae_images) {
+  if (!out || !parent) return PNPI_EINVAL;
+  if (parent->warena_borrowed) return fail(parent, PNPI_ESTATE, "pnpi_create_shared: the parent itself borrows its weights; share from the owner");
+  return create_impl(out, &parent->cfg, parent->device, hip_stream, max_unet_rows, max_vae_images, parent);
+}
+static int create_impl(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images, pnpi_ctx* parent) {
   pnpi_ctx* c = new pnpi_ctx();
   *out = c;
   c->cfg = *cfg; c->device = device; c->st = (hipStream_t)hip_stream; c->max_rows = max_unet_rows; c->max_vae = max_vae_images;
@@ -1585,10 +1598,17 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
   // pass 1: measure the weight arena; pass 2: real pointers
   build_model(c);
   const size_t wbytes = align_up(c->warena.peak + 4096, 4096);
-  CKH(hipMalloc((void**)&c->warena.base, wbytes));
-  CKH(hipMemsetAsync(c->warena.base, 0, wbytes, c->st));
+  if (parent) {
+    if (parent->warena.cap != wbytes) return fail(c, PNPI_ESTATE, "pnpi_create_shared: the parent's weight arena has another size");
+    c->warena.base = parent->warena.base; c->warena_borrowed = true;
+  } else {
+    CKH(hipMalloc((void**)&c->warena.base, wbytes));
+    CKH(hipMemsetAsync(c->warena.base, 0, wbytes, c->st));
+  }
   c->warena.cap = wbytes; c->warena.reset(); c->warena.peak = 0;
   build_model(c);
+  if (parent)      // the same deterministic layout: every slot points at the parent's packed tensor and is loaded iff the parent's is
+    for (auto& kv : c->slots) { auto it = parent->slots.find(kv.first); kv.second.loaded = it != parent->slots.end() && it->second.loaded; }
   // small persistent buffers
   const int C0 = g.block_out_channels[0], TE = 4 * C0;
   c->splitk_bytes = ((size_t)96 << 20) + (size_t)(max_unet_rows > 12 ? max_unet_rows - 12 : 0) * ((size_t)8 << 20);   // grows with the rows per launch
@@ -1684,7 +1704,7 @@ int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* 
 void pnpi_destroy(pnpi_ctx* c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->st);
-  void* bufs[] = {c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial, c->gn_bwd_ws,
+  void* bufs[] = {c->warena_borrowed ? nullptr : (void*)c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial, c->gn_bwd_ws,
                   c->temb_table, c->temb_h, c->temb_emb, c->bias_scratch, c->bias_tab, c->tkv.base, c->rows_ident};
   for (void* b : bufs) (void)hipFree(b);
   if (c->tape) {
@@ -1703,6 +1723,7 @@ static void invalidate_derived(pnpi_ctx* c) {     // caches of functions of the 
 
 int pnpi_load_weights(pnpi_ctx* c, const pnpi_named_tensor* ts, int n) {
   if (!c || !ts) return PNPI_EINVAL;
+  if (c->warena_borrowed) return fail(c, PNPI_ESTATE, "this context borrows its weights (pnpi_create_shared): load them into the owning context");
   invalidate_derived(c);
   for (int i = 0; i < n; ++i) {
     const pnpi_named_tensor& t = ts[i];

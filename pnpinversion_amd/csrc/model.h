@@ -176,6 +176,7 @@ struct pnpi_ctx {
   bool dry;
   int tf_index = 0;   // transformer block counter of the forward in flight (MasaCtrl start_layer)
   Bump warena, persist, temp, ctrl_arena;
+  bool warena_borrowed = false;                     // pnpi_create_shared: warena.base is the parent's (never freed / written here)
   float* splitk_ws; size_t splitk_bytes;
   float* gn_partial;
   float* temb_table;      // [n_train][C0] fp32 sinusoid table

@@ -98,7 +98,9 @@ def _desc_array(ctrls):
 
 
 class NativeEngine:
-    def __init__(self, cfg: ModelConfig, device=None, max_unet_rows=4, max_vae_images=2):
+    def __init__(self, cfg: ModelConfig, device=None, max_unet_rows=4, max_vae_images=2, share_weights_with=None):
+        """share_weights_with: another NativeEngine on the same device -- this context then borrows its packed weight arena
+        (pnpi_create_shared: no second copy of the 1.9 GB) and is ready without load_state_dict; the other engine must outlive it."""
         if not torch.cuda.is_available():
             raise RuntimeError("NativeEngine needs an AMD GPU (gfx950); there is no CPU fallback")
         self.lib = _capi.load_library()
@@ -108,10 +110,16 @@ class NativeEngine:
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
-            st = self.lib.pnpi_create(C.byref(self.h), C.byref(self._ccfg), self.device.index or 0, C.c_void_p(stream),
-                                      max_unet_rows, max_vae_images)
+            if share_weights_with is not None:
+                if share_weights_with.device != self.device or share_weights_with.cfg != cfg:
+                    raise ValueError("share_weights_with: same device and model configuration required")
+                self._weights_owner = share_weights_with          # keep the owner alive as long as this context
+                st = self.lib.pnpi_create_shared(C.byref(self.h), share_weights_with.h, C.c_void_p(stream), max_unet_rows, max_vae_images)
+            else:
+                st = self.lib.pnpi_create(C.byref(self.h), C.byref(self._ccfg), self.device.index or 0, C.c_void_p(stream),
+                                          max_unet_rows, max_vae_images)
         if st != 0:
-            msg = self.lib.pnpi_last_error(self.h)
+            msg = self.lib.pnpi_last_error(self.h if self.h else (share_weights_with.h if share_weights_with is not None else self.h))
             raise _capi.PnpiError(st, msg.decode() if msg else "?")
         self.max_unet_rows = max_unet_rows
         self.max_vae_images = max_vae_images

@@ -210,10 +210,12 @@ class NativeTextEncoder:
 
 class NativePipeline:
     def __init__(self, cfg: ModelConfig = SD1, device=None, max_unet_rows=12, max_vae_images=2, tokenizer=None, text_encoder=None,
-                 scheduler=None):
+                 scheduler=None, share_weights_with=None):
         """text_encoder: None = seeded stand-in embedding (no CLIP weights needed); "native" = the CLIP text transformer of
-        libpnpi (load its weights with load_state_dict(..., clip_sd=...)); or any callable with the CLIPTextModel protocol."""
-        self.engine = NativeEngine(cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images)
+        libpnpi (load its weights with load_state_dict(..., clip_sd=...)); or any callable with the CLIPTextModel protocol.
+        share_weights_with: another NativePipeline -- a further context (own stream / workspaces) on ITS packed weights, no copy."""
+        self.engine = NativeEngine(cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images,
+                                   share_weights_with=share_weights_with.engine if share_weights_with is not None else None)
         self.device = self.engine.device
         self.unet = NativeUNet(self.engine)
         self.vae = NativeVAE(self.engine)

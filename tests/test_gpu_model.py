@@ -353,3 +353,38 @@ def test_attention_store_keep_maps_and_npi_slerp(tiny):
     om = torch.acos(((l64 / l64.norm(dim=1, keepdim=True)) * (h64 / h64.norm(dim=1, keepdim=True))).sum(1))
     want = (torch.sin(0.7 * om) / torch.sin(om)).unsqueeze(1) * l64 + (torch.sin(0.3 * om) / torch.sin(om)).unsqueeze(1) * h64
     assert rel(got, want.reshape(lo.shape)) < 1e-6
+
+
+def test_shared_weight_arena_contexts():
+    """pnpi_create_shared: a further context borrows the parent's packed weights -- same arena pointer (no second copy), ready without a
+    load, bit-identical forward on its own stream, and it refuses to load weights itself."""
+    import ctypes as C
+    from pnpinversion_amd import _capi
+    from pnpinversion_amd.config import SMALL64
+    from pnpinversion_amd.engine import NativeEngine
+    cfg = SMALL64
+    main = NativeEngine(cfg, max_unet_rows=4, max_vae_images=1)
+    usd, vsd = weights.unet_state_dict(cfg, 3), weights.vae_state_dict(cfg, 3)
+    main.load_state_dict(usd, vsd)
+    free_before = torch.cuda.mem_get_info()[0]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        child = NativeEngine(cfg, max_unet_rows=4, max_vae_images=1, share_weights_with=main)
+    pa, pb, na, nb = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+    assert main.lib.pnpi_weight_arena(main.h, C.byref(pa), C.byref(na)) == 0 and main.lib.pnpi_weight_arena(child.h, C.byref(pb), C.byref(nb)) == 0
+    assert pa.value == pb.value and na.value == nb.value
+    assert child.missing_weights()[0] == 0
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 4, cfg.sample_size, cfg.sample_size, generator=g).cuda()
+    ctx = weights.synth_context(cfg, 2, seed=6).cuda()
+    a = main.unet(lat, 481, ctx)
+    with torch.cuda.stream(side):
+        b = child.unet(lat, 481, ctx)
+        side.synchronize()
+    assert torch.equal(a, b)
+    with pytest.raises(_capi.PnpiError, match="borrows its weights"):
+        child.load_state_dict(usd, vsd)
+    with pytest.raises(_capi.PnpiError):
+        NativeEngine(cfg, max_unet_rows=4, max_vae_images=1, share_weights_with=child)      # share from the owner, not from a borrower
+    child.close()
+    main.close()
