@@ -4,7 +4,9 @@ Unlike tools/autotune2.py (one GEMM in a loop, operands warm in the 256 MB MALL)
 has (residual, GEGLU, GroupNorm statistics, V^T) and the cache state it really meets inside a forward.
 usage: fwd_tune.py [rows ...] (default 12 1) -> gpurun_out/fwd_tune_b<rows>.json (the format tools/gen_tile_table.py reads)
 FWD_TUNE_WORK=ctxgrad (rows = 1): the workload is one recording forward + reverse walk (pnpi_unet_context_grad, the null-text iteration), so
-the dgrad shapes of the walk are tuned too -> gpurun_out/fwd_tune_b1bwd.json"""
+the dgrad shapes of the walk are tuned too -> gpurun_out/fwd_tune_b1bwd.json
+FWD_TUNE_WORK=vae (rows = images per call, default 1 2): one VAE encode + one decode at 512 x 512 (the edit runs 1 + 5 of them per image)
+-> gpurun_out/fwd_tune_b<rows>vae.json"""
 import csv, json, os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pnpinversion_amd import weights
@@ -15,7 +17,9 @@ NAME = {0: "128", 1: "64", 3: "256m", 4: "320", 5: "256n", 6: "256x320", 7: "256
 SINGLE = [0, 1, 3, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8, 16, 17]
 SPLIT_CFGS = [0, 1, 4, 5, 11, 14, 16, 17]
 SPLITS = [2, 3, 4, 6, 8, 12, 16]
-eng = NativeEngine(SD1, max_unet_rows=max(rows_list + [4]), max_vae_images=1)
+VAE = os.environ.get("FWD_TUNE_WORK") == "vae"
+if VAE and not sys.argv[1:]: rows_list = [1, 2]
+eng = NativeEngine(SD1, max_unet_rows=4 if VAE else max(rows_list + [4]), max_vae_images=max(rows_list) if VAE else 1)
 eng.load_state_dict({k: v.cuda() for k, v in weights.unet_state_dict(SD1, 0).items()}, {k: v.cuda() for k, v in weights.vae_state_dict(SD1, 0).items()})
 lib = eng.lib
 def setk(**kw):
@@ -30,7 +34,11 @@ for rows in rows_list:
     lat = torch.randn(rows, 4, 64, 64, device="cuda"); ctx = torch.randn(rows, 77, 768, device="cuda")
     d_eps = torch.randn(rows, 4, 64, 64, device="cuda") * 256
     work = (lambda: eng.unet_context_grad(lat, 500, ctx, d_eps)) if BWD else (lambda: eng.unet(lat, 500, None))
-    eng.text_kv_precompute(ctx)
+    if VAE:
+        img = torch.rand(rows, 3, 512, 512, device="cuda") * 2 - 1; zlat = torch.randn(rows, 4, 64, 64, device="cuda")
+        work = lambda: (eng.vae_encode(img), eng.vae_decode(zlat))
+    else:
+        eng.text_kv_precompute(ctx)
     combos = [(-1, 0)] + [(c, 0) for c in SINGLE] + [(c, s) for s in SPLITS for c in SPLIT_CFGS]
     if os.environ.get("FWD_TUNE_CFGS"):        # quick look at a few configurations: FWD_TUNE_CFGS="3,14"
         combos = [(-1, 0)] + [(int(c), 0) for c in os.environ["FWD_TUNE_CFGS"].split(",")]
@@ -68,4 +76,4 @@ for rows in rows_list:
     for s in sorted(shapes, key=lambda s: -(s["us"].get("auto", 0) - min(v for k, v in s["us"].items() if k != "auto")))[:12]:
         b = min(((k, v) for k, v in s["us"].items() if k != "auto"), key=lambda kv: kv[1])
         print("  (%d,%d,%d,%d) x%d auto=%.0f best=%s %.0f" % (s["M"], s["N"], s["K"], s["ks"], s["launches"], s["us"].get("auto", 0), b[0], b[1]), flush=True)
-    json.dump({"rows": rows, "per_forward": True, "shapes": shapes}, open("gpurun_out/fwd_tune_b%d%s.json" % (rows, "bwd" if BWD else ""), "w"), indent=1)
+    json.dump({"rows": rows, "per_forward": True, "shapes": shapes}, open("gpurun_out/fwd_tune_b%d%s.json" % (rows, "bwd" if BWD else ("vae" if VAE else "")), "w"), indent=1)
