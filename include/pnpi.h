@@ -351,6 +351,11 @@ size_t pnpi_op_attention_bwd_scratch_bytes(int Nq, int Nk, int dh);
 int pnpi_edit_loop_uncond_steps(pnpi_ctx* ctx, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
                                 const int* timesteps_host, float guidance_scale, int prox, float quantile, const float* uncond_steps,
                                 int uncond_first_only, float* latents_out);
+/* pnpi_edit_loop_uncond_steps with the reconstruction guidance of pnpi_edit_loop (recon nullable): the edit pass of
+ * P2PEditor.edit_image_null_text_inversion_proximal_guidanca(use_reconstruction_guidance=True), models/p2p_editor.py:607-627. */
+int pnpi_edit_loop_uncond_steps_recon(pnpi_ctx* ctx, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
+                                      const int* timesteps_host, float guidance_scale, int prox, float quantile, const float* uncond_steps,
+                                      int uncond_first_only, const pnpi_recon_desc* recon, float* latents_out);
 int pnpi_unet_context_grad(pnpi_ctx* ctx, const float* latents, int t, const float* context, const float* d_eps, float* eps_out,
                            float* d_context_out);
 int pnpi_null_text_optimize(pnpi_ctx* ctx, const float* ddim_latents, const float* ctx_uncond, const float* ctx_cond, int nsteps,

@@ -121,6 +121,7 @@ SYMBOLS = {
     "pnpi_op_attention_bwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pnpi_op_attention_bwd_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "pnpi_edit_loop_uncond_steps": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, _i, _vp]),
+    "pnpi_edit_loop_uncond_steps_recon": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, _i, C.POINTER(ReconDesc), _vp]),
     "pnpi_unet_context_grad": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pnpi_null_text_optimize": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "pnpi_null_latent_calculate": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int), _f, _i, _f, _vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]),

@@ -2252,6 +2252,15 @@ int pnpi_edit_loop_uncond_steps(pnpi_ctx* c, const float* x_T, int nimg, const f
                         uncond_first_only);
 }
 
+// the same with reconstruction guidance (null-text-inversion+proximal-guidance, use_reconstruction_guidance=True: p2p_editor.py:620-627)
+int pnpi_edit_loop_uncond_steps_recon(pnpi_ctx* c, const float* x_T, int nimg, const float* context4, const pnpi_ctrl_desc* ctrl_host, int nsteps,
+                                      const int* ts, float gs, int prox, float quantile, const float* uncond_steps, int uncond_first_only,
+                                      const pnpi_recon_desc* recon, float* latents_out) {
+  if (!uncond_steps) return PNPI_EINVAL;
+  return edit_loop_impl(c, x_T, nimg, context4, nullptr, 1, ctrl_host, nsteps, ts, gs, prox, quantile, recon, latents_out, uncond_steps,
+                        uncond_first_only);
+}
+
 /* offset_calculate + npass guidance-forward passes of P2PEditor.edit_image_directinversion (p2p_editor.py:99-160) advanced in
  * lock step: every pass walks the same timesteps and pass p's step i needs only noise_loss[i], which the offset pass produces
  * at the same step -- so one UNet launch per step serves all (1 + npass) * 4 * nimg rows. */

@@ -393,17 +393,22 @@ class NativeEngine:
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int32))
         return ts, ts.ctypes.data_as(C.POINTER(C.c_int))
 
-    def edit_loop_uncond_steps(self, x_T, context4, uncond_steps, ctrls, timesteps, guidance_scale, first_only=False, prox=None, quantile=0.7):
-        """edit_loop with per-step unconditional embeddings [steps, nimg, 77, D] (null-text inversion)."""
+    def edit_loop_uncond_steps(self, x_T, context4, uncond_steps, ctrls, timesteps, guidance_scale, first_only=False, prox=None, quantile=0.7,
+                               recon=None):
+        """edit_loop with per-step unconditional embeddings [steps, nimg, 77, D] (null-text inversion); recon as in edit_loop."""
         xT, ctx, us = self._f32(x_T), self._f32(context4), self._f32(uncond_steps)
         nimg = xT.shape[0]
         out = torch.empty(nimg, 2, *xT.shape[1:], device=self.device)
         ts, tsp = self._ts(timesteps)
         arr = _desc_array(ctrls)
         mode = {None: 0, "l0": 1, "l1": 2}[prox]
-        self._call("pnpi_edit_loop_uncond_steps", _p(xT), nimg, _p(ctx), arr, len(timesteps), tsp, float(guidance_scale), mode, float(quantile),
-                   _p(us), int(bool(first_only)), _p(out))
-        self._keep = (xT, ctx, us, ts, arr, ctrls)
+        rd, ref = None, None
+        if recon is not None:
+            ref = self._f32(recon["ref_image"]).reshape(nimg, *xT.shape[1:]).contiguous()
+            rd = _capi.ReconDesc(ref.data_ptr(), float(recon["recon_lr"]), int(recon["recon_t"]), int(recon.get("dilate_mask") or 0))
+        self._call("pnpi_edit_loop_uncond_steps_recon", _p(xT), nimg, _p(ctx), arr, len(timesteps), tsp, float(guidance_scale), mode, float(quantile),
+                   _p(us), int(bool(first_only)), C.byref(rd) if rd is not None else None, _p(out))
+        self._keep = (xT, ctx, us, ts, arr, ctrls, ref, rd)
         return out
 
     def unet_context_grad(self, latents, t, context, d_eps):

@@ -121,11 +121,9 @@ def p2p_guidance_forward(model, prompt, controller, num_inference_steps: int = 5
     if prox is not None and batch_size != 2:
         raise NotImplementedError("the proximal step takes its quantile over the (source, target) pair")
     if per_step is not None:      # null-text inversion: the step's embedding on every unconditional row (:56-57) or the first only (:92)
-        if recon is not None:
-            raise NotImplementedError("reconstruction guidance with per-step unconditional embeddings")
         out = model.engine.edit_loop_uncond_steps(latent.reshape(1, *latent.shape[-3:]), context[None], per_step,
                                                   [tables] if tables is not None else None, model.scheduler.timesteps.numpy(), guidance_scale,
-                                                  first_only=single_branch, prox=prox, quantile=quantile)
+                                                  first_only=single_branch, prox=prox, quantile=quantile, recon=recon)
     else:
         out = model.engine.edit_loop(latent.reshape(1, *latent.shape[-3:]), context[None], None, [tables] if tables is not None else None,
                                      model.scheduler.timesteps.numpy(), guidance_scale, prox=prox, quantile=quantile, recon=recon)

@@ -232,22 +232,29 @@ class P2PEditor:
     def edit_image_null_text_inversion(self, image_path, prompt_src, prompt_tar, guidance_scale=7.5, cross_replace_steps=0.4,
                                        self_replace_steps=0.6, blend_word=None, eq_params=None, is_replace_controller=False,
                                        single_branch=False, proximal=None, quantile=0.7, use_reconstruction_guidance=False,
+                                       recon_t=400, recon_lr=0.1, use_inversion_guidance=False, dilate_mask=1,
                                        num_inner_steps=10, return_stages=False):
-        """models/p2p_editor.py:199-259 (null-text inversion + P2P), :261-322 (single branch), :550-638 (+ proximal guidance with the
-        arguments run_editing_p2p.py passes): NullInversion.invert = DDIM inversion + per-step optimisation of the unconditional
-        embedding (pnpi_null_text_optimize), then the two plain guidance passes with the per-step embeddings."""
-        if use_reconstruction_guidance:
-            raise NotImplementedError("reconstruction guidance with per-step unconditional embeddings is not built")
+        """models/p2p_editor.py:199-259 (null-text inversion + P2P), :261-322 (single branch), :550-638 (+ proximal guidance, with the
+        reconstruction guidance of :620-627 when use_reconstruction_guidance is set): NullInversion.invert = DDIM inversion + per-step
+        optimisation of the unconditional embedding (pnpi_null_text_optimize), then the two guidance passes with the per-step embeddings."""
         image_gt, side = self._load(image_path)
         self.ldm_stable.scheduler.set_timesteps(self.num_ddim_steps)
         inv = NullInversion(model=self.ldm_stable, num_ddim_steps=self.num_ddim_steps)
         _, _, x_stars, uncond_embeddings = inv.invert(image_gt=image_gt, prompt=prompt_src, guidance_scale=guidance_scale,
                                                       num_inner_steps=num_inner_steps)
+        # Reconstruction guidance pulls the predicted x0 towards the ENCODED source image.  The reference hands this editor
+        # NullInversion.invert's second return value for it -- the decoded uint8 image (inversion.py:190-194,227-234), which
+        # DDIMSchedulerDev.step cannot subtract from a latent: its use_reconstruction_guidance=True raises.  The encoded latent is
+        # x*_0 = ddim_latents[0], what NegativePromptInversion.invert returns in that position (inversion.py:72-76,96) for the same code.
+        image_enc_latent = x_stars[0]
         base = p2p_guidance_forward_single_branch if single_branch else p2p_guidance_forward
+        on = use_reconstruction_guidance or use_inversion_guidance
 
         def fwd(**k):   # the reconstruction pass runs without the proximal step (edit_stage=False, p2p_editor.py:577-594)
             if proximal is not None and len(k["prompt"]) == 2:
-                return proximal_guidance_forward(num_inference_steps=self.num_ddim_steps, edit_stage=True, prox=proximal, quantile=quantile, **k)
+                return proximal_guidance_forward(num_inference_steps=self.num_ddim_steps, edit_stage=True, prox=proximal, quantile=quantile,
+                                                 image_enc=image_enc_latent if use_reconstruction_guidance else None,
+                                                 recon_lr=recon_lr if on else 0, recon_t=recon_t if on else 1000, dilate_mask=dilate_mask, **k)
             return base(num_inference_steps=self.num_ddim_steps, **k)
         out = self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                               self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
@@ -266,7 +273,8 @@ class P2PEditor:
         """models/p2p_editor.py:550-638 (the reference's spelling).  recon_* / use_inversion_guidance / dilate_mask only matter with
         reconstruction guidance (image_enc is None otherwise, and the inversion-guidance branch is dead code: :87-89 precedence)."""
         return self.edit_image_null_text_inversion(image_path, prompt_src, prompt_tar, proximal=proximal, quantile=quantile,
-                                                   use_reconstruction_guidance=use_reconstruction_guidance, **kw)
+                                                   use_reconstruction_guidance=use_reconstruction_guidance, recon_t=recon_t, recon_lr=recon_lr,
+                                                   use_inversion_guidance=use_inversion_guidance, dilate_mask=dilate_mask, **kw)
 
     def edit_image_null_latent_inversion(self, image_path, prompt_src, prompt_tar, **kw):
         """models/p2p_editor.py:640-705: DirectInversion.invert_null_latent (pnpi_null_latent_calculate) + the two direct-inversion passes"""

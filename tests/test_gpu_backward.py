@@ -395,3 +395,41 @@ def test_null_text_editor_against_reference_golden():
                 blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)})
     assert panel2.size == (2048, 512) and np.isfinite(np.asarray(panel2, dtype=np.float32)).all()
     pipe.engine.close()
+
+
+def test_null_text_proximal_guidance_with_reconstruction_guidance():
+    """null-text-inversion+proximal-guidance with use_reconstruction_guidance=True (pnpi_edit_loop_uncond_steps_recon: per-step embeddings
+    AND the masked pull of the predicted x0 towards the encoded source, models/p2p_editor.py:607-627).  The reference's own call fails
+    (it passes a uint8 image where the scheduler needs a latent), so there is no golden: the pull must act on the target row only where
+    the reference's formula says (recon_t window), leave the l0 proximal edit finite and change nothing when recon_lr = 0."""
+    import numpy as np
+    from PIL import Image
+    from pnpinversion_amd import weights
+    from pnpinversion_amd.config import SMALL64
+    from pnpinversion_amd.p2p_editor import P2PEditor
+    from pnpinversion_amd.pipeline import NativePipeline
+    from pnpinversion_amd.text import SyntheticTextEncoder
+    import os
+    GOLD = os.path.join(os.path.dirname(__file__), "golden")
+    cfg, steps = SMALL64, 3
+    pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
+    pipe.load_state_dict(weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2))
+    ed = P2PEditor(["null-text-inversion+proximal-guidance"], "cuda", num_ddim_steps=steps, pipeline=pipe)
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    src, tgt = "a cat sitting on a wooden chair", "a dog sitting on a wooden chair"
+    kw = dict(proximal="l0", quantile=0.75, num_inner_steps=3, return_stages=True)
+    _, plain = ed.edit_image_null_text_inversion(img, src, tgt, **kw)
+    _, recon = ed.edit_image_null_text_inversion(img, src, tgt, use_reconstruction_guidance=True, recon_lr=1, recon_t=400, **kw)
+    _, off = ed.edit_image_null_text_inversion(img, src, tgt, use_reconstruction_guidance=True, recon_lr=0, recon_t=400, **kw)
+    a, b, c = plain["latents"].cpu(), recon["latents"].cpu(), off["latents"].cpu()
+    assert torch.isfinite(b).all()
+    assert torch.equal(a, c)                                   # recon_lr = 0: the plain proximal edit, bit for bit
+    assert (a - b).abs().max().item() > 1e-3                   # the pull acts
+    z0 = recon["x_stars"][0].cpu()
+    # with recon_lr = 1 the pulled pixels of the predicted x0 ARE the encoded source: the edit moves towards it
+    assert (b[1] - z0[0]).norm() < (a[1] - z0[0]).norm()
+    # through the dispatch, with the sweep script's arguments
+    panel = ed("null-text-inversion+proximal-guidance", image_path=img, prompt_src=src, prompt_tar=tgt, proximal="l0", quantile=0.75,
+               use_reconstruction_guidance=True, recon_lr=1, recon_t=400)
+    assert panel.size == (2048, 512)
+    pipe.engine.close()
