@@ -365,14 +365,11 @@ class P2PEditor:
         """A second library context on its own HIP stream, borrowing the main context's packed weight arena (pnpi_create_shared): the inversion of
         the NEXT image runs there while this image's lock-step loop runs on the main context."""
         if getattr(self, "_inverter", None) is None:
-            from .pipeline import NativeTextEncoder
             main = self.ldm_stable
             torch.cuda.synchronize(main.device)
             self._inv_stream = torch.cuda.Stream(device=main.device)
             with torch.cuda.device(main.device), torch.cuda.stream(self._inv_stream):
-                native_text = isinstance(main.text_encoder, NativeTextEncoder)
-                p = NativePipeline(main.engine.cfg, device=main.device, max_unet_rows=4, max_vae_images=2, tokenizer=main.tokenizer,
-                                   text_encoder="native" if native_text else main.text_encoder, share_weights_with=main)
+                p = main.peer(max_unet_rows=4, max_vae_images=2)
                 self._inv_stream.synchronize()
                 p.scheduler.set_timesteps(self.num_ddim_steps)
             self._inverter = p
@@ -381,18 +378,14 @@ class P2PEditor:
     def _peer_editors(self, n):
         """n further P2PEditors, each on a library context of its own (own HIP stream, own workspaces, the SAME packed weight arena --
         pnpi_create_shared borrows the main context's, no copy): `edit_stream_in_flight` spreads the images of a sweep over this editor and them."""
-        from .pipeline import NativeTextEncoder
         peers = self.__dict__.setdefault("_peers", [])
         main = self.ldm_stable
         while len(peers) < n:
             torch.cuda.synchronize(main.device)
             stream = torch.cuda.Stream(device=main.device)
             with torch.cuda.device(main.device), torch.cuda.stream(stream):
-                native_text = isinstance(main.text_encoder, NativeTextEncoder)
                 # one image per context: 12 UNet rows (the lock-step loop) are the most any method string launches
-                p = NativePipeline(main.engine.cfg, device=main.device, max_unet_rows=min(main.engine.max_unet_rows, 12),
-                                   max_vae_images=min(main.engine.max_vae_images, 2), tokenizer=main.tokenizer,
-                                   text_encoder="native" if native_text else main.text_encoder, share_weights_with=main)
+                p = main.peer(max_unet_rows=min(main.engine.max_unet_rows, 12), max_vae_images=min(main.engine.max_vae_images, 2))
                 stream.synchronize()
             peer = P2PEditor(self.method_list, self.device, num_ddim_steps=self.num_ddim_steps, pipeline=p)
             peers.append((peer, stream))
