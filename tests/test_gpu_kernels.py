@@ -165,6 +165,63 @@ def test_gemm_transposed_columns_through_lds_epilogue(ctx, cfg, col0, N, T, vt_l
     assert rel_err(vt, ref[:, col0:].reshape(Bn, T, N - col0).permute(0, 2, 1)) < 2e-3
 
 
+def _pp_random_gemm_cases(n, seed):
+    """(M, N, K, cfg, split, has_bias, has_res, alpha) drawn from the ranges the ping-pong kernel serves: M to beyond 2^16 (a linear layer's x
+    coordinate), N any multiple of 8 (ragged n-tiles, the weight-row clamp), 1 .. 40 K-tiles, split-K with empty last slices."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        cfg = rng.choice((16, 17))
+        M = rng.choice((rng.randint(1, 600), rng.randint(600, 5000), rng.randint(30000, 70000)))
+        N = 8 * rng.randint(1, 170)
+        K = 64 * rng.randint(1, 40 if M < 6000 else 6)
+        split = rng.choice((0, 0, 0, 2, 3, 5, 7)) if K >= 256 else 0
+        out.append((M, N, K, cfg, split, rng.random() < 0.7, rng.random() < 0.5, rng.choice((1.0, 1.0, 0.5))))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,cfg,split,has_bias,has_res,alpha", _pp_random_gemm_cases(28, 20260926))
+def test_pingpong_gemm_random_shapes(ctx, M, N, K, cfg, split, has_bias, has_res, alpha):
+    a = h16(M, K, seed=M % 97)
+    w = h16(N, K, scale=1.0 / math.sqrt(K), seed=N % 89)
+    bias = torch.randn(N, device=DEV) if has_bias else None
+    res = h16(M, N, seed=3) if has_res else None
+    out = torch.full((M, N), float("nan"), dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_gemm", ptr(a), K, ptr(w), K, M, N, K, alpha, ptr(bias), ptr(res), ptr(out), N, 1 << 30, None, 0, 0, 1, cfg, split)
+    ref = alpha * (a.float() @ w.float().t())
+    if has_bias:
+        ref = ref + bias
+    if has_res:
+        ref = ref + res.float()
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 2e-3, (rel_err(out, ref), max_err(out, ref))
+
+
+def _pp_random_conv_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        cfg = rng.choice((16, 17))
+        C1 = 64 * rng.randint(1, 4)
+        C2 = 64 * rng.randint(0, 2)
+        H = rng.choice((7, 8, 12, 16, 24, 33))
+        stride, pad, ups = rng.choice(((1, 1, 0), (1, 1, 0), (2, 1, 0), (2, 0, 0), (1, 1, 1)))
+        if ups:
+            H = min(H, 12)
+        B = rng.randint(1, 5)
+        N = 8 * rng.randint(4, 90)
+        split = rng.choice((0, 0, 2, 4))
+        out.append((B, C1, C2, H, N, stride, pad, ups, cfg, split))
+    return out
+
+
+@pytest.mark.parametrize("B,C1,C2,H,N,stride,pad,ups,cfg,split", _pp_random_conv_cases(20, 4242))
+def test_pingpong_conv_random_shapes(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split):
+    test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split)
+
+
 # ------------------------------------------------------------------------------------------------ conv
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
