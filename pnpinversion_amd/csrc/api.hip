@@ -122,6 +122,11 @@ static TransformerW make_transformer(pnpi_ctx* c, const std::string& pre, int C,
   reg_mat(c, tb + ".attn1.to_q.weight", t.w_qkv, C, C, 1, C, C, 0, t.dh, t.Dp);
   reg_mat(c, tb + ".attn1.to_k.weight", t.w_qkv, C, C, 1, C, C, hd, t.dh, t.Dp);
   reg_mat(c, tb + ".attn1.to_v.weight", t.w_qkv, C, C, 1, C, C, 2 * hd, t.dh, t.Dp);
+  t.b_qkv_aug = nullptr;
+  if (t.Dp == 64 && t.dh == 40) {      // SD-1.x's 64 x 64 level: one padding column of K and V carries a constant 1 (see TransformerW)
+    t.b_qkv_aug = walloc_f(c, (size_t)3 * hd);
+    c->aug_biases.push_back({t.b_qkv_aug, t.heads, t.Dp, t.dh});
+  }
   t.o1 = make_lin(c, tb + ".attn1.to_out.0", C, C);
   t.w_q2 = walloc_h(c, (size_t)hd * C);
   reg_mat(c, tb + ".attn2.to_q.weight", t.w_q2, C, C, 1, C, C, 0, t.dh, t.Dp);
@@ -163,6 +168,7 @@ static int temb_total_channels(const pnpi_model_config& g) {
 static void build_model(pnpi_ctx* c) {
   const pnpi_model_config& g = c->cfg;
   c->slots.clear();
+  c->aug_biases.clear();
   UNetW& u = c->unet;
   u = UNetW();
   const int n = g.n_blocks, C0 = g.block_out_channels[0], TE = 4 * C0;
@@ -359,8 +365,10 @@ struct Tape {
   float* d_ctx = nullptr;                             // [rows * ctx_len * cross_dim] fp32
   void* attn_scratch = nullptr; size_t attn_scratch_bytes = 0;
 };
+static int g_attn_aug = 1;           // tuning "attn_aug" = 0: the 64-wide flash kernel ignores the augmented column (A/B)
 static int g_vt_perm = 1;            // tuning "attn_vt_perm": V^T of the 4096-token self-attention sites in the permuted key order (A/B)
 static int g_attn_bwd_flash = 1;     // tuning "attn_bwd_flash": self-attention backward without the [N][N] matrices in memory (0: the materialised form everywhere)
+static int g_op_attention_aug = 0;       // tuning "op_attention_aug": pnpi_op_attention is handed K / V^T with 1.0 in column / row dh (kernel tests)
 static int g_op_attention_vt_perm = 0;   // tuning "op_attention_vt_perm": pnpi_op_attention is handed a permuted V^T (kernel tests)
 static inline bool taping(pnpi_ctx* c) { return c->tape && c->tape->rec && !c->dry; }
 // a recording forward (or the dry run that sizes the arenas for one) keeps every activation and takes the plain-layout transformer block
@@ -550,11 +558,12 @@ static int transformer_fwd(pnpi_ctx* c, const TransformerW& t, const half_t* x, 
   const int vperm = (g_vt_perm && !c->attn_cb && N % 16 == 0 && attn_flash_uses_dma64(t.Dp, N, 0)) ? 1 : 0;
   {
     VtOut v; v.outT = vt; v.col0 = 2 * hd; v.ld = ldv; v.f32 = 0; v.rpb = N; v.perm16 = vperm;
-    CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, nullptr, nullptr, 0, qk, 2 * hd, 1.f, &v, 2.0 * M * 3.0 * C * C));
+    CK(op_gemm(c, n1, C, M, C, t.w_qkv, C, 3 * hd, t.b_qkv_aug, nullptr, 0, qk, 2 * hd, 1.f, &v, 2.0 * M * 3.0 * C * C));
   }
   half_t* ao = talloc(c, (size_t)M * C);
   {
     AttnP a; a.q = qk; a.ldq = 2 * hd; a.q_off = 0; a.k = qk; a.ldk = 2 * hd; a.k_off = hd; a.vt = vt; a.ldv = ldv; a.vt_perm = vperm;
+    a.aug = (t.b_qkv_aug && g_attn_aug) ? 1 : 0;      // K / V column dh hold 1.0 (the projection above added b_qkv_aug)
     a.o = ao; a.ldo = C; a.heads = t.heads; a.Nq = N; a.Nk = N; a.Dp = t.Dp; a.dh = t.dh; a.scale = scale;
     const bool rep = edit && cur_step >= cd.self_lo && cur_step < cd.self_hi && N <= cd.self_max_tokens;
     const bool masa_step = cd.masa_step_list ? (cur_step >= 0 && cur_step < (int)cd.masa_step_on.size() && cd.masa_step_on[cur_step]) : cur_step >= cd.masa_start_step;
@@ -1609,6 +1618,14 @@ static int create_impl(pnpi_ctx** out, const pnpi_model_config* cfg, int device,
   build_model(c);
   if (parent)      // the same deterministic layout: every slot points at the parent's packed tensor and is loaded iff the parent's is
     for (auto& kv : c->slots) { auto it = parent->slots.find(kv.first); kv.second.loaded = it != parent->slots.end() && it->second.loaded; }
+  else
+    for (const pnpi_ctx::AugBias& ab : c->aug_biases) {      // constants of the arena (not part of any checkpoint): the memset above left zeros
+      std::vector<float> hb((size_t)3 * ab.heads * ab.Dp, 0.f);
+      for (int part = 1; part < 3; ++part)
+        for (int hh = 0; hh < ab.heads; ++hh) hb[(size_t)part * ab.heads * ab.Dp + hh * ab.Dp + ab.dh] = 1.f;
+      CKH(hipMemcpyAsync(ab.p, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice, c->st));
+      CKH(hipStreamSynchronize(c->st));                        // hb is a temporary
+    }
   // small persistent buffers
   const int C0 = g.block_out_channels[0], TE = 4 * C0;
   c->splitk_bytes = ((size_t)96 << 20) + (size_t)(max_unet_rows > 12 ? max_unet_rows - 12 : 0) * ((size_t)8 << 20);   // grows with the rows per launch
@@ -2411,6 +2428,8 @@ int pnpi_set_tuning(const char* key, int value) {
   if (!strcmp(key, "temb_cache")) { g_temb_cache = value; return 0; }
   if (!strcmp(key, "gn_inline_rows")) { norm_set_tuning_gn_inline_rows(value); return 0; }
   if (!strcmp(key, "attn_vt_perm")) { g_vt_perm = value; return 0; }
+  if (!strcmp(key, "attn_aug")) { g_attn_aug = value; return 0; }
+  if (!strcmp(key, "op_attention_aug")) { g_op_attention_aug = value; return 0; }
   if (!strcmp(key, "op_attention_vt_perm")) { g_op_attention_vt_perm = value; return 0; }
   if (!strcmp(key, "attn_bwd_flash")) { g_attn_bwd_flash = value; return 0; }
   return igemm_set_tuning(key, value) == 0 ? 0 : PNPI_EINVAL;
@@ -2737,6 +2756,7 @@ int pnpi_op_attention(pnpi_ctx* c, const void* q, int ldq, int q_off, const void
   a.vt = (const half_t*)vt; a.ldv = ldv; a.o = (half_t*)o; a.ldo = ldo; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.Dp = Dp; a.dh = dh;
   a.scale = scale; a.rows = rows_dev; a.nrows = nrows;
   a.vt_perm = (g_op_attention_vt_perm && attn_flash_uses_dma64(Dp, Nk, 0)) ? 1 : 0;
+  a.aug = g_op_attention_aug;
   CK(launch_attn_flash(a, c->st));
   return 0;
 }

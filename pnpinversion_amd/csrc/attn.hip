@@ -217,7 +217,17 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // KSQ: 16-wide k-steps of S = K Q^T actually run -- 3 when the head is at most 48 wide (d = 40: columns 48 .. 63 of q and k are zero
 // padding, their products exact zeros): a quarter of the S MFMAs and K fragment reads, bit-identical results.
-template <bool VPERM, int KSQ = 4>
+//
+// AUG (round 4; d = 40 heads, AttnP::aug): the kernel is VALU-bound -- per 64-key tile a wave issues 14 MFMAs (448 cycles) but ~940 cycles of
+// VALU work on its 32 scores per lane (quarter-rate v_exp_f32 528, the exponent's fma 124, the row-sum adds 132, max / convert 160).  Two of
+// those passes move into the MFMAs through ONE padding dimension of the 40 -> 64 head (the producer projection's bias writes 1.0 into column
+// d = 40 of every K row and every V row, api.hip b_qkv_aug):
+//   * Q is pre-scaled by scale * log2(e) and carries -m_run in its column 40, so S' = K Q'^T comes out of the matrix pipe already in the
+//     log2 domain and already shifted by the running maximum: P = exp2(S') with no per-element fma.  m_run is kept exactly representable
+//     in fp16 (it is a reference point, not the true maximum: the deferred-rescale threshold of 8 covers the rounding);
+//   * V^T row 40 is all ones, so O^T row 40 accumulates sum_k P -- with the same fp16-rounded P the numerator uses: no per-element add.
+// Same results to rounding (Q is rounded once more after the scaling); ~30 % fewer VALU cycles per tile.
+template <bool VPERM, int KSQ = 4, bool AUG = false>
 __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   constexpr int DP = 64, KS = 4, OT = 2;
   constexpr int STAGE = 2 * 64 * 128;   // K tile + V^T tile, bytes
@@ -243,13 +253,18 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
   }
+  const float c = p.scale * 1.44269504088896340736f;
+  if (AUG) {
+    const half_t ch = (half_t)c;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) qf[ks] = qf[ks] * ch;          // S in the log2 domain straight from the MFMA
+  }
   floatx16 O[OT];
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[ot][r] = 0.f;
-  float mrun = -INFINITY, lrun = 0.f;
-  const float c = p.scale * 1.44269504088896340736f;
+  float mrun = AUG ? 0.f : -INFINITY, lrun = 0.f;     // AUG: the reference point carried in Q's column 40 (log2 domain, fp16-representable)
 
   // DMA lane roles: instruction j (1 KiB = 8 rows) of a 64-row tile; this wave issues j = 2*wave, 2*wave+1 for K and for V^T
   const half_t* kptr[2];
@@ -302,6 +317,35 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[st][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    half8 pf[2][2];
+    float psum = 0.f;
+    if (AUG) {
+      // s is S' = c S - m_run already.  The first tile always moves the reference point (its scores were computed against 0), later tiles
+      // when the tile's maximum is more than 8 above it; the new point is rounded to fp16 so that Q's column 40 holds it exactly.
+      const bool grow = it == 0 || mloc > 8.0f;
+      float delta = 0.f;
+      if (__any(grow)) {
+        const float target = mrun + ((it == 0 || mloc > 0.f) ? mloc : 0.f);
+        const half_t mh = (half_t)target;
+        const float mnew = (float)mh;
+        delta = mnew - mrun;                                          // exact: both ends are fp16 values
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[ot][r] *= alpha;             // row 40 (the running sum) included
+        mrun = mnew;
+        if (h == 1) qf[2][0] = (half_t)(-mnew);                       // column 40 = k-step 2, upper half-wave, element 0
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[st][r] -= delta;             // this tile was computed against the old point (rare path)
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[st][r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(s[st][r]);
+    } else {
     const bool grow = (mloc - mrun) * c > 8.0f;     // deferred rescale, see attn_flash_kernel
     if (__any(grow)) {
       const float mnew = fmaxf(mrun, mloc);
@@ -314,8 +358,6 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
       mrun = mnew;
     }
     const float mc = mrun * c;
-    float psum = 0.f;
-    half8 pf[2][2];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -324,6 +366,7 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
         psum += pv;
         pf[st][r >> 3][r & 7] = (half_t)pv;
       }
+    }
     lrun += psum;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
@@ -346,10 +389,16 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
         }
     }
   }
-  const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+  float ltot;
+  if (AUG) {                       // O^T row 40 = accumulator 4 of the second 32-row tile in the lower half-wave
+    const float lrow = O[1][4], lother = __shfl_xor(lrow, 32, 64);
+    ltot = h == 0 ? lrow : lother;
+  } else {
+    ltot = lrun + __shfl_xor(lrun, 32, 64);
+  }
   const float inv = 1.f / ltot;
   // recording forward of the null-text path: log2 sum_k 2^(c S) per query, for the backward kernel (mrun is the reference exponent of lrun)
-  if (p.lse && qok && h == 0) p.lse[((size_t)orow * p.heads + head) * p.Nq + qtok] = mrun * c + __log2f(ltot);
+  if (p.lse && qok && h == 0) p.lse[((size_t)orow * p.heads + head) * p.Nq + qtok] = (AUG ? mrun : mrun * c) + __log2f(ltot);
   if (qok) {
     half_t* op = p.o + ((size_t)orow * p.Nq + qtok) * p.ldo + head * p.dh;
 #pragma unroll
@@ -384,7 +433,11 @@ int launch_attn_flash(const AttnP& p, hipStream_t st) {
   static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
   if (p.Dp == 64 && p.Nk % 64 == 0 && p.Nk >= 128 && !no_dma && !p.causal) {
     static const bool ksq3 = !(getenv("PNPI_ATTN_KSQ4") != nullptr);      // PNPI_ATTN_KSQ4: always four k-steps (A/B)
-    if (p.dh <= 48 && ksq3) {
+    static const bool no_aug = getenv("PNPI_ATTN_NOAUG") != nullptr;         // A/B: ignore AttnP::aug
+    if (p.aug && p.dh == 40 && ksq3 && !no_aug) {
+      if (p.vt_perm) attn_flash_dma64_kernel<true, 3, true><<<grid, 256, 0, st>>>(p);
+      else attn_flash_dma64_kernel<false, 3, true><<<grid, 256, 0, st>>>(p);
+    } else if (p.dh <= 48 && ksq3) {
       if (p.vt_perm) attn_flash_dma64_kernel<true, 3><<<grid, 256, 0, st>>>(p);
       else attn_flash_dma64_kernel<false, 3><<<grid, 256, 0, st>>>(p);
     } else {

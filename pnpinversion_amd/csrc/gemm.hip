@@ -565,7 +565,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
                          !p.geglu && g_vt_lds;
     const bool epi_ok = (vt_none_ || vt_lds_) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) &&
                         (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.vt_perm16 || p.rows_per_batch % 16 == 0);
-    if (!dma_ok || (split == 1 && !epi_ok) || (split > 1 && p.N % 4 != 0) || p.nbatch > 1) cfg = 0;     // (batched launches stay on the 4-wave kernels)
+    // its DMA addresses are 32-bit byte offsets under a 2 GiB buffer descriptor: operands beyond that stay on the 64-bit-pointer kernels
+    const double lim = 2147483648.0 - 1048576.0;
+    const bool off32_ok = 2.0 * p.B * p.H * p.W * (double)(p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) < lim && 2.0 * (double)p.N * p.ldw < lim;
+    if (!dma_ok || !off32_ok || (split == 1 && !epi_ok) || (split > 1 && p.N % 4 != 0) || p.nbatch > 1) cfg = 0;     // (batched launches stay on the 4-wave kernels)
   }
   const bool c64 = cfg == 1 || cfg == 8 || cfg == 11 || cfg == 12, c256m = cfg == 3 || cfg == 6 || cfg == 7 || cfg == 16;
   const bool cpp = cfg == 16 || cfg == 17;      // the 8-wave ping-pong kernel: 16 = 256 x 256, 17 = 192 x 320

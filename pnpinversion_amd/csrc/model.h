@@ -54,6 +54,8 @@ struct TransformerW {
   NormW gn, ln1, ln2, ln3;
   ConvW proj_in, proj_out;
   half_t* w_qkv;      // [3*heads*Dp][C]   (self-attention, heads zero-padded to Dp)
+  float* b_qkv_aug;   // [3*heads*Dp] or nullptr: zeros, but 1.0 at column dh of every K head and every V head -- d = 40 heads padded to 64:
+                      // the 64-wide flash kernel takes its max shift and row sum through the MFMAs with it (attn.hip, AUG)
   LinW o1;            // [C][C] + bias
   half_t* w_q2;       // [heads*Dp][C]
   half_t* w_kv2;      // [2*heads*Dp][cross_dim]
@@ -176,6 +178,8 @@ struct pnpi_ctx {
   bool dry;
   int tf_index = 0;   // transformer block counter of the forward in flight (MasaCtrl start_layer)
   Bump warena, persist, temp, ctrl_arena;
+  struct AugBias { float* p; int heads, Dp, dh; };
+  std::vector<AugBias> aug_biases;                  // the b_qkv_aug vectors of this build (filled after the arena exists)
   bool warena_borrowed = false;                     // pnpi_create_shared: warena.base is the parent's (never freed / written here)
   float* splitk_ws; size_t splitk_bytes;
   float* gn_partial;

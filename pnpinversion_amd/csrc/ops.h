@@ -105,6 +105,8 @@ struct AttnP {
   int nrows;
   int causal = 0;                 // 1: key j is masked for query i when j > i (CLIP text encoder)
   int vt_perm = 0;                // 1: vt is stored in the permuted key order (only the 64-wide LDS-DMA self-attention kernel reads it)
+  int aug = 0;                    // 1: column d = dh of every K row and every V row (V^T row dh) holds 1.0 (the producer's bias wrote it):
+                                  //    the 64-wide LDS-DMA kernel then takes the max shift and the row sum through the MFMAs (attn.hip, AUG)
   float* lse = nullptr;           // optional [out_row][heads][Nq]: log2-domain log-sum-exp of every query (recording forward of the null-text path)
 };
 int launch_attn_flash(const AttnP& p, hipStream_t st);

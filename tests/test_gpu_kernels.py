@@ -467,6 +467,55 @@ def test_attention_flash_permuted_vt_and_its_producer(ctx, B, heads, N):
     assert torch.equal(o, o2)          # the same numbers in the same order: bit-identical to the plain layout
 
 
+@pytest.mark.parametrize("B,heads,N,perm", [(1, 8, 4096, 1), (2, 2, 256, 0), (1, 2, 1024, 1)])
+def test_attention_flash_augmented_column(ctx, B, heads, N, perm):
+    """The 64-wide LDS-DMA kernel with AttnP::aug (d = 40 heads): column 40 of every K row and row 40 of V^T hold 1.0 (in the model the q | k | v
+    projection's bias writes them); the kernel then takes the running-max shift through Q's column 40 and the row sum through V^T's row 40
+    (no per-element fma / add).  Against fp32 softmax attention, against the plain kernel on the same inputs, and with keys that force the
+    reference point to move late in the key walk (a spike at key 3 * N / 4) and queries whose scores are all far below zero (first-tile path)."""
+    dh, Dp = 40, 64
+    q, k, v, qb, kb, vt, ldv = make_qkv(B, heads, N, N, dh, Dp, seed=27)
+    # a late spike: key j0 is 6 x query i0 -> its logit is far above everything seen before it; and a query far from every key
+    i0, j0 = 5, (3 * N) // 4
+    k[:, :, j0] = 6.0 * q[:, :, i0]
+    q[:, :, 9] = -8.0 * k[:, :, :64].mean(dim=2)
+    kb.view(B, N, heads, Dp)[..., :dh] = k.permute(0, 2, 1, 3)
+    qb.view(B, N, heads, Dp)[..., :dh] = q.permute(0, 2, 1, 3)
+    scale = dh ** -0.5
+    ref = ((q.float() @ k.float().transpose(-1, -2) * scale).softmax(-1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, heads * dh)
+    rows = torch.arange(B, dtype=torch.int32, device=DEV).repeat_interleave(4).reshape(B, 4).contiguous()
+    pos = torch.arange(N, device=DEV)
+    vtx = vt.clone()
+    if perm:
+        swap = (((pos >> 2) ^ (pos >> 3)) & 1).bool()
+        vtx[..., torch.where(swap, pos ^ 12, pos)] = vt[..., pos]
+
+    def run(aug):
+        kk, vv = kb.clone(), vtx.clone()
+        if aug:
+            kk.view(B, N, heads, Dp)[..., dh] = 1.0
+            vv.view(B, heads, Dp, -1)[:, :, dh, :] = 1.0
+        o = torch.zeros(B, N, heads * dh, dtype=torch.half, device=DEV)
+        assert ctx.lib.pnpi_set_tuning(b"op_attention_aug", aug) == 0 and ctx.lib.pnpi_set_tuning(b"op_attention_vt_perm", perm) == 0
+        try:
+            ctx.call("pnpi_op_attention", ptr(qb), heads * Dp, 0, ptr(kk), heads * Dp, 0, ptr(vv), ldv, ptr(o), heads * dh, heads, N, N, Dp, dh, scale,
+                     ptr(rows), B)
+            torch.cuda.synchronize()
+        finally:
+            ctx.lib.pnpi_set_tuning(b"op_attention_aug", 0)
+            ctx.lib.pnpi_set_tuning(b"op_attention_vt_perm", 0)
+        return o
+
+    plain, aug = run(0), run(1)
+    assert torch.isfinite(aug).all()
+    assert rel_err(plain, ref) < 3e-3, rel_err(plain, ref)
+    assert rel_err(aug, ref) < 3e-3, rel_err(aug, ref)
+    assert rel_err(aug, plain.float()) < 2e-3, rel_err(aug, plain.float())
+    # the spiked query row and the far-away query row individually
+    for i in (i0, 9):
+        assert rel_err(aug[:, i], ref[:, i]) < 5e-3, (i, rel_err(aug[:, i], ref[:, i]))
+
+
 def test_attention_row_indirection(ctx):
     # self-attention replacement: output row 3 uses q,k of row 2 and its own v (attention_control.py:258-263)
     B, heads, N, dh, Dp = 4, 2, 128, 40, 64
