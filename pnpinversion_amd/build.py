@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libpnpi.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "step.hip", "bwd.hip", "api.hip"]
-HEADERS = ["common.h", "ops.h", "model.h", "tile_table.inc", "igemm_dma.inc", "igemm_pp.inc", os.path.join("..", "..", "include", "pnpi.h")]
+HEADERS = ["common.h", "ops.h", "model.h", "tile_table.inc", "igemm_dma.inc", "igemm_pp.inc", "api_weights.inc", "api_graph.inc", "api_backward.inc", "api_vae.inc", "api_ctrl.inc", os.path.join("..", "..", "include", "pnpi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-value"]
 # Per-file flags.  step.hip: the reference rounds every multiply / add separately (no FMA contraction).  attn.hip: keep the MFMA
 # accumulators in VGPRs (gfx950's unified file) -- the softmax between the two MFMAs is VALU work on the S accumulators, and in
