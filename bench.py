@@ -249,6 +249,43 @@ def main():
                                     "GBps": (v["bytes"] / (v["total_ms"] * 1e-3) / 1e9) if v["total_ms"] > 0 and v["bytes"] > 0 else None}
                                 for k, v in classes.items()}}
 
+    # the two loops of one more edit timed on their own (rank 0, outside the timed region): the 50 one-row DDIM-inversion forwards and the
+    # 50 twelve-row lock-step steps of the dual-branch loop north_star's 40 % target is stated on (models/p2p/p2p_guidance_forward.py:135-173)
+    phases = None
+    if rank == 0 and args.schedule == "lockstep":
+        marks = {}
+
+        def timed(name, fn):
+            def wrapper(*a, **k):
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                out_ = fn(*a, **k)
+                torch.cuda.synchronize()
+                marks[name] = marks.get(name, 0.0) + time.perf_counter() - t_
+                return out_
+            return wrapper
+
+        orig_inv, orig_edit = eng.ddim_invert, eng.direct_edit
+        eng.ddim_invert, eng.direct_edit = timed("invert", orig_inv), timed("lockstep", orig_edit)
+        try:
+            torch.cuda.synchronize()
+            t_all = time.perf_counter()
+            one_edit(999)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t_all
+        finally:
+            eng.ddim_invert, eng.direct_edit = orig_inv, orig_edit
+        if "invert" in marks and "lockstep" in marks:
+            n = args.ddim_steps
+            loop_flop = n * 12 * (UNET_GFLOP - TEXT_KV_GFLOP) * 1e9 + 12 * TEXT_KV_GFLOP * 1e9      # text K / V projected once per loop
+            phases = {"ddim_inversion_ms": marks["invert"] * 1e3, "one_row_forward_ms": marks["invert"] * 1e3 / n,
+                      "lockstep_loop_ms": marks["lockstep"] * 1e3, "twelve_row_step_ms": marks["lockstep"] * 1e3 / n,
+                      "lockstep_loop_tflops": loop_flop / marks["lockstep"] / 1e12,
+                      "lockstep_loop_mfma_frac": loop_flop / marks["lockstep"] / 1e12 / MFMA_PEAK_TFLOPS,
+                      "rest_ms": (t_all - marks["invert"] - marks["lockstep"]) * 1e3,
+                      "note": "one more edit with a device synchronisation around pnpi_ddim_invert and pnpi_direct_edit (host wall clock); "
+                              "rest = VAE encode / decodes, text encoder, controller tables, panel"}
+
     # extra (never `value`): the pruned-equivalent schedule of SURVEY Note D, FLOPs from the library's counters
     pruned = None
     if args.schedule == "lockstep" and not args.no_extras:
@@ -458,7 +495,7 @@ def main():
             "bcast_ms": bcast.get("ms"), "bcast_mb": (bcast.get("bytes", 0) / 1e6) if bcast else None,   # the start-up weight broadcast (untimed set-up)
             "whole_path_tflops_per_gpu": per_rank_flops / dt / 1e12,
             "whole_path_mfma_frac": per_rank_flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
-            "roofline": roofline,
+            "roofline": roofline, "phases": phases,
         }
         if pruned is not None:
             out["pruned_schedule"] = pruned
