@@ -290,7 +290,12 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
  * 16-byte fragment load ("op_attention_vt_perm": pnpi_op_attention is handed such a V^T -- kernel tests); "igemm_res_late" (0) residual
  * added in the store loop; "igemm_force_cfg" (-1) / "igemm_force_split" (0) one tile id / split-K for every launch (sweeps);
  * "igemm_table_near" (1) nearest-row-count table entry for untabled M; "igemm_v128", "igemm_v64", "igemm_v256", "igemm_v320",
- * "igemm_v256n" variant of a tile id; "tile_order" (-1) XCD traversal order. */
+ * "igemm_v256n" variant of a tile id; "tile_order" (-1) XCD traversal order; "igemm_vpp" (0) ablations of the 8-wave ping-pong kernel
+ * (1 no MFMAs, 2 no DMA, 3 DMA only, 4 MFMAs only -- all but 0 produce garbage, timing only); "igemm_tapin" (0) the ping-pong kernel
+ * walks a 3 x 3 convolution's K channel-slab-major; "igemm_pp_only_m" / "_n" / "_k" (0) the table's ping-pong entries apply only to
+ * launches with that M / N / K (n < 0: to none; tools/pp_bisect.py); "attn_aug" (1) the 40-wide flash self-attention carries the running
+ * maximum and the row sum in the padding column of Q / K / V (0: explicit shift and sum on the VALU; the column is written either way and ignored);"op_attention_aug" (0) pnpi_op_attention is handed K and V whose column 40 holds 1.0
+ * and runs that kernel (kernel tests). */
 int pnpi_set_tuning(const char* key, int value);
 /* Host-only query of the measured tile table launch_igemm consults before its cost model (no device work; used by the CPU tests):
  * returns 1 for an exact {M, N, K, ksize} entry, 2 when the same layer (N, K, ksize) is listed at another row count and the entry
