@@ -102,8 +102,9 @@ typedef struct {
   float lb_threshold_sub;          /* th[1] = 0.3 */
   /* kind 2 with explicit lists (MutualSelfAttentionControl(layer_idx=, step_idx=), masactrl.py:24-37: membership tests at :61).  Both
    * optional; when given they REPLACE the corresponding window above. */
-  unsigned masa_layer_mask;        /* bit b set: transformer block b (execution order 0..15) is in layer_idx; 0 = the start_layer window */
-  int masa_n_steps;                /* length of masa_step_on_host; 0 = the start_step window */
+  unsigned masa_layer_mask;        /* bit b set: transformer block b (execution order 0..15) is in layer_idx; 0 = the start_layer window.
+                                      Bit 31 = "a list was given": alone it is the EMPTY list (no block matches, control off) */
+  int masa_n_steps;                /* length of masa_step_on_host; 0 = the start_step window (an empty step_idx list: one 0 byte) */
   const unsigned char* masa_step_on_host;   /* [masa_n_steps]: 1 where the denoising step is in step_idx (steps past the end: off) */
 } pnpi_ctrl_desc;
 

@@ -204,15 +204,6 @@ class NativeTextEncoder:
     def to(self, device):
         return self
 
-    def peer(self, **override):
-        """A further pipeline of the same class on this one's packed weights (pnpi_create_shared: own HIP stream = torch's current
-        stream, own workspaces), built from this pipeline's own constructor options; `override` replaces some (e.g. max_unet_rows)."""
-        kw = dict(self._ctor)
-        kw.pop("scheduler_cls")
-        kw["device"] = self.device
-        kw.update(override)
-        return type(self)(share_weights_with=self, **kw)
-
     def __call__(self, input_ids, **kw):
         return (self.engine.text_encode(input_ids),)
 
@@ -225,7 +216,7 @@ class NativePipeline:
         share_weights_with: another NativePipeline -- a further context (own stream / workspaces) on ITS packed weights, no copy."""
         # what a further context on the same weights is built from (P2PEditor's in-flight / stage-overlap peers): every constructor option
         self._ctor = dict(cfg=cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images, tokenizer=tokenizer,
-                          text_encoder=text_encoder, scheduler_cls=type(scheduler) if scheduler is not None else None)
+                          text_encoder=text_encoder)
         self.engine = NativeEngine(cfg, device=device, max_unet_rows=max_unet_rows, max_vae_images=max_vae_images,
                                    share_weights_with=share_weights_with.engine if share_weights_with is not None else None)
         self.device = self.engine.device
@@ -244,10 +235,12 @@ class NativePipeline:
 
     def peer(self, **override):
         """A further pipeline of the same class on this one's packed weights (pnpi_create_shared: own HIP stream = torch's current
-        stream, own workspaces), built from this pipeline's own constructor options; `override` replaces some (e.g. max_unet_rows)."""
+        stream, own workspaces), built from this pipeline's own constructor options and a copy of its scheduler (same alphas, bound to
+        the new context); `override` replaces some (e.g. max_unet_rows)."""
+        import copy
         kw = dict(self._ctor)
-        kw.pop("scheduler_cls")
         kw["device"] = self.device
+        kw["scheduler"] = copy.copy(self.scheduler)
         kw.update(override)
         return type(self)(share_weights_with=self, **kw)
 
