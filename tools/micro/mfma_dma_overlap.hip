@@ -1,0 +1,95 @@
+// Microbenchmark: do the matrix pipe and the global -> LDS DMA stream of one CU overlap when NOTHING synchronises them?
+// One workgroup of 8 waves per CU (128 KB of LDS requested).  Waves 0-3 (one per SIMD) issue v_mfma_f32_16x16x32_f16 back to back on
+// register operands: 128 per "K-tile" = the 2048 matrix-pipe cycles of a 256 x 256 x 64 tile.  Waves 4-7 stream 64 KB per "K-tile" into
+// LDS with buffer_load_dwordx4 ... lds (16 instructions of 1 KB per wave, two K-tiles in flight), from a region every workgroup shares
+// (L2 hits) or from a private one (HBM).  Modes: MFMA waves alone, DMA waves alone, both.  If both ~ max(alone) the two streams overlap
+// and the ping-pong kernel's sum-like behaviour (312 us against 205 / 195) is its own synchronisation; if both ~ sum, the
+// hardware serialises them.
+// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_dma_overlap mfma_dma_overlap.hip     Run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr;
+
+template <int MODE>   // 1 = MFMA waves only, 2 = DMA waves only, 3 = both
+__global__ void __launch_bounds__(512, 2) overlap_kernel(const char* base, size_t region, int priv, int ktiles, float* sink) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < 4) {
+    if (!(MODE & 1)) return;
+    floatx4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(float)(lane & 3); b[j] = (_Float16)(float)(j & 1); }
+    for (int t = 0; t < ktiles; ++t) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.f) sink[blockIdx.x] = s;
+  } else {
+    if (!(MODE & 2)) return;
+    const int w = wave - 4;
+    // lane l of an instruction fetches 16 bytes of row (l >> 3), chunk (l & 7): eight 128-byte rows, row stride 23040 bytes (K = 11520 halfs)
+    const size_t stride = 23040;
+    const char* src = base + (priv ? (size_t)blockIdx.x * region : 0);
+    const unsigned lane_off = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+    unsigned kofs = 0;                                  // walks along the rows, 128 bytes per K-tile; wraps inside the region
+    const unsigned rows = (unsigned)(region / stride) & ~127u;   // rows the region holds (a multiple of the 128 this wave group touches per K-tile)
+    unsigned row0 = 0;
+    for (int t = 0; t < ktiles; ++t) {
+      char* dst = smem + ((t & 1) * 4 + w) * 16384;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned off = (unsigned)((row0 + (w * 16 + i) * 8) * stride) + kofs + lane_off;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0x80000000, 0x00020000), (lptr)(dst + i * 1024), 16, (int)off, 0, 0, 0);
+      }
+      kofs += 128;
+      if (kofs + 128 > stride) { kofs = 0; row0 += 512; if (row0 + 512 > rows) row0 = 0; }
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sink && lane == 0 && ((int*)smem)[w * 4096] == 0x7fffffff) sink[blockIdx.x] = 1.f;
+  }
+}
+
+template <int MODE>
+static float run(const char* buf, size_t region, int priv, int ktiles, float* sink) {
+  hipFuncSetAttribute((const void*)overlap_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  overlap_kernel<MODE><<<256, 512, 128 * 1024>>>(buf, region, priv, 20, sink);
+  hipDeviceSynchronize();
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    overlap_kernel<MODE><<<256, 512, 128 * 1024>>>(buf, region, priv, ktiles, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
+int main() {
+  const size_t region = (size_t)12 << 20;     // 12 MB: 512 rows x 23040 bytes; private mode: 256 x 12 MB = 3 GB
+  char* buf; if (hipMalloc(&buf, region * 256) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipMemset(buf, 0, region * 256);
+  float* sink; hipMalloc(&sink, 4096);
+  const int ktiles = 180;
+  printf("%-28s %10s %10s %10s   (us, 180 K-tiles: 23040 MFMAs per MFMA wave = 2048 cycles per K-tile, 64 KB DMA per CU per K-tile)\n", "source", "MFMA", "DMA", "both");
+  for (int priv = 0; priv <= 1; ++priv) {
+    const float m = run<1>(buf, region, priv, ktiles, sink), d = run<2>(buf, region, priv, ktiles, sink), b = run<3>(buf, region, priv, ktiles, sink);
+    printf("%-28s %10.1f %10.1f %10.1f   both / max = %.2f, both / sum = %.2f; DMA alone %.1f B/clk/CU at 2.4 GHz\n", priv ? "private 12 MB per CU (HBM)" : "one shared 12 MB (L2 / MALL)", m, d,
+           b, b / (m > d ? m : d), b / (m + d), 65536.0 * ktiles / (d * 1e-6) / 2.4e9);
+  }
+  printf("%s\n", hipGetLastError() == hipSuccess ? "ok" : "ERR");
+  return 0;
+}
