@@ -361,3 +361,40 @@ def test_native_unet_attention_site_markers_without_the_reference():
         unet._cb_for = p
         unet.set_controller(None)
         assert eng.callback is None and unet._cb_for is None
+
+
+def test_masactrl_descriptor_windows_and_lists():
+    """MutualSelfAttentionControl(start_step, start_layer, layer_idx, step_idx) (models/masactrl/masactrl.py:14-37, membership tests at :61)
+    -> pnpi_ctrl_desc kind 2: the windows travel as two integers, explicit lists as a block mask (bit 31 = "a list was given") and a
+    per-step flag array; host side only, no GPU."""
+    from pnpinversion_amd.engine import MasaCtrlTables
+    from pnpinversion_amd.masactrl.masactrl import MutualSelfAttentionControl
+
+    def membership(d, block, step):       # what api_graph.inc's masa_layer / masa_step evaluate from the descriptor
+        layer = ((d.masa_layer_mask >> block) & 1) == 1 and block < 31 if d.masa_layer_mask else block >= d.masa_start_layer
+        if d.masa_n_steps > 0 and bool(d.masa_step_on_host):
+            st = 0 <= step < d.masa_n_steps and d.masa_step_on_host[step] == 1
+        else:
+            st = step >= d.masa_start_step
+        return layer and st
+
+    # the default windows: no mask, no step array
+    c = MutualSelfAttentionControl(4, 10)
+    t = c.tables(); d = t.desc()
+    assert (d.kind, d.masa_start_step, d.masa_start_layer, d.masa_layer_mask, d.masa_n_steps) == (2, 4, 10, 0, 0)
+    for block in range(16):
+        for step in range(50):
+            assert membership(d, block, step) == (step in c.step_idx and block in c.layer_idx)
+    # lists that ARE the windows stay windows; anything else becomes mask / flags, including the empty lists and entries past the UNet
+    assert MutualSelfAttentionControl(4, 10, layer_idx=list(range(10, 16)), step_idx=list(range(4, 50))).tables().desc().masa_layer_mask == 0
+    for layer_idx, step_idx in (([0, 3, 15], [0, 7, 49]), ([], [5]), ([12], []), ([2, 40, 31], [60, 1]), (list(range(16)), list(range(50)))):
+        c = MutualSelfAttentionControl(4, 10, layer_idx=layer_idx, step_idx=step_idx)
+        t = c.tables(); d = t.desc()
+        assert d.masa_layer_mask >> 31 == 1 and d.masa_n_steps >= 1
+        for block in range(16):
+            for step in range(64):
+                assert membership(d, block, step) == (step in step_idx and block in layer_idx), (layer_idx, step_idx, block, step)
+    # the step array outlives desc(): the descriptor points into the tables object
+    t = MasaCtrlTables(step_idx=[3])
+    d = t.desc()
+    assert d.masa_n_steps == 4 and [d.masa_step_on_host[i] for i in range(4)] == [0, 0, 0, 1]
