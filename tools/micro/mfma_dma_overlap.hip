@@ -102,6 +102,88 @@ __global__ void __launch_bounds__(256, 1) fused_kernel(const char* base, size_t 
   if (s == 12345.f) sink[blockIdx.x] = s;
 }
 
+// The same with the fragment traffic of a 128 x 128 wave tile: 64 accumulator tiles (256 registers: AGPRs), per half K-tile 8 + 8 ds_read_b128 into
+// a second fragment buffer while the 64 MFMAs of the current one issue, 8 DMA instructions spread between them.  What the reads fetch is whatever the
+// DMA left in LDS: timing only.
+__global__ void __launch_bounds__(256, 1) fused_reads_kernel(const char* base, size_t panel_bytes, int ktiles, float* sink) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t stride = 23040;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  if (idx >= 30) return;
+  const char* srcA = base + (size_t)(xcd * 6 + idx / 5) * panel_bytes, *srcW = base + (size_t)(48 + idx % 5) * panel_bytes;
+  const unsigned lane_off = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+  floatx4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // fragment addressing of the ping-pong kernel: lane l reads row (l & 15) of a 16-row block of 128-byte rows, chunk (l >> 4) ^ swizzle
+  // reads as the product kernel issues them: inline ds_read_b128 the compiler neither reorders nor waits for (its own waits after LDS-DMA
+  // instructions would be vmcnt waits), one explicit lgkmcnt(0) per half K-tile
+  const unsigned fr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (lane & 15) * 128 + ((((unsigned)lane >> 4) ^ (((unsigned)lane & 15) >> 1)) << 4);
+  auto rd = [&](unsigned addr) { half8 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; };
+  half8 fa[2][8], fb[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { fa[0][i] = rd(fr + ((wave >> 1) * 1024 + i * 128) * 16); fb[0][i] = rd(fr + (4096 + (wave & 1) * 1024 + i * 128) * 16); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int cur = 0;
+  for (int t = 0; t < ktiles; ++t) {
+    char* dst = smem + ((t & 1) * 4 + wave) * 16384;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // half K-tiles (k-steps of 32)
+      const unsigned buf = (unsigned)(t & 1) * 65536u;
+      const int nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {        // next fragments: the other k-step of this buffer / the first of the next
+        fa[nxt][i] = rd(fr + buf + ((wave >> 1) * 1024 + i * 128) * 16 + (h ? 0 : 64));
+        fb[nxt][i] = rd(fr + buf + (2048 + (wave & 1) * 1024 + i * 128) * 16 + (h ? 0 : 64));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        {   // one DMA instruction per 8 MFMAs
+          const unsigned blk = (unsigned)(wave * 16 + h * 8 + i);
+          const unsigned off = ((blk * 8) & 255) * (unsigned)stride + (unsigned)(t % 180) * 128 + lane_off;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)((blk & 32) ? srcW : srcA), 0, (int)0x80000000, 0x00020000), (lptr)(dst + (h * 8 + i) * 1024), 16, (int)off, 0,
+                                                   0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+  if (s == 12345.f) sink[blockIdx.x] = s;
+}
+
+static float run_fused_reads(const char* buf, size_t panel, int ktiles, float* sink) {
+  hipFuncSetAttribute((const void*)fused_reads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  fused_reads_kernel<<<256, 256, 128 * 1024>>>(buf, panel, 20, sink);
+  hipDeviceSynchronize();
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    fused_reads_kernel<<<256, 256, 128 * 1024>>>(buf, panel, ktiles, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
 template <int FUSED>
 static float run_fused(const char* buf, size_t panel, int ktiles, float* sink) {
   hipFuncSetAttribute((const void*)fused_kernel<FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -153,6 +235,7 @@ int main() {
     const float m = run_fused<3>(buf, panel, ktiles, sink), d = run_fused<2>(buf, panel, ktiles, sink), b = run_fused<1>(buf, panel, ktiles, sink);
     printf("%-28s %10.1f %10.1f %10.1f   both / max = %.2f, both / sum = %.2f   (ONE wave per SIMD issuing the MFMAs and the DMA, operand panels of a 12288 x 1280 x 11520 GEMM)\n",
            "fused, GEMM operand panels", m, d, b, b / (m > d ? m : d), b / (m + d));
+    printf("%-28s %10s %10s %10.1f   (the same with the fragment reads of a 128 x 128 wave tile, 64 accumulator tiles, a barrier per K-tile)\n", "fused + fragment reads", "", "", run_fused_reads(buf, panel, ktiles, sink));
   }
   printf("%s\n", hipGetLastError() == hipSuccess ? "ok" : "ERR");
   return 0;
