@@ -105,6 +105,9 @@ __global__ void __launch_bounds__(256, 1) fused_kernel(const char* base, size_t 
 // The same with the fragment traffic of a 128 x 128 wave tile: 64 accumulator tiles (256 registers: AGPRs), per half K-tile 8 + 8 ds_read_b128 into
 // a second fragment buffer while the 64 MFMAs of the current one issue, 8 DMA instructions spread between them.  What the reads fetch is whatever the
 // DMA left in LDS: timing only.
+// HONEST = 1: what two K-tile buffers allow -- a buffer is free once every wave has read its second k-step (the middle of the iteration: vmcnt(0) +
+// barrier there), K-tile t + 2 is requested in the second half of iteration t (16 instructions, two per eight MFMAs) and must have landed by the middle of t + 1.
+template <int HONEST>
 __global__ void __launch_bounds__(256, 1) fused_reads_kernel(const char* base, size_t panel_bytes, int ktiles, float* sink) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,12 +144,15 @@ __global__ void __launch_bounds__(256, 1) fused_reads_kernel(const char* base, s
         fb[nxt][i] = rd(fr + buf + (2048 + (wave & 1) * 1024 + i * 128) * 16 + (h ? 0 : 64));
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (HONEST && h == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        {   // one DMA instruction per 8 MFMAs
-          const unsigned blk = (unsigned)(wave * 16 + h * 8 + i);
+#pragma unroll
+        for (int q = 0; q < (HONEST ? 2 : 1); ++q) {   // one DMA instruction per 8 MFMAs (HONEST: two, second half of the iteration only)
+          if (HONEST && h == 0) break;
+          const unsigned blk = (unsigned)(wave * 16 + (HONEST ? i * 2 + q : h * 8 + i));
           const unsigned off = ((blk * 8) & 255) * (unsigned)stride + (unsigned)(t % 180) * 128 + lane_off;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)((blk & 32) ? srcW : srcA), 0, (int)0x80000000, 0x00020000), (lptr)(dst + (h * 8 + i) * 1024), 16, (int)off, 0,
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)((blk & 32) ? srcW : srcA), 0, (int)0x80000000, 0x00020000), (lptr)(dst + (blk & 15) * 1024), 16, (int)off, 0,
                                                    0, 0);
         }
 #pragma unroll
@@ -156,8 +162,7 @@ __global__ void __launch_bounds__(256, 1) fused_reads_kernel(const char* base, s
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       cur = nxt;
     }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!HONEST) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   float s = 0.f;
@@ -168,15 +173,101 @@ __global__ void __launch_bounds__(256, 1) fused_reads_kernel(const char* base, s
   if (s == 12345.f) sink[blockIdx.x] = s;
 }
 
+template <int HONEST>
 static float run_fused_reads(const char* buf, size_t panel, int ktiles, float* sink) {
-  hipFuncSetAttribute((const void*)fused_reads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipFuncSetAttribute((const void*)fused_reads_kernel<HONEST>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  fused_reads_kernel<<<256, 256, 128 * 1024>>>(buf, panel, 20, sink);
+  fused_reads_kernel<HONEST><<<256, 256, 128 * 1024>>>(buf, panel, 20, sink);
   hipDeviceSynchronize();
   float best = 1e9f;
   for (int r = 0; r < 3; ++r) {
     hipEventRecord(e0);
-    fused_reads_kernel<<<256, 256, 128 * 1024>>>(buf, panel, ktiles, sink);
+    fused_reads_kernel<HONEST><<<256, 256, 128 * 1024>>>(buf, panel, ktiles, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
+// A smaller tile with THREE K-tile buffers (192 x 224 x 64: 52 KB per K-tile, 156 KB; wave tile 96 x 112 = 6 x 7 accumulator tiles): 13 DMA
+// instructions and 84 MFMAs per wave and K-tile, 6 + 7 fragment reads per half K-tile, requests two K-tiles ahead (which three buffers allow).
+__global__ void __launch_bounds__(256, 1) fused_small_kernel(const char* base, size_t panel_bytes, int ktiles, float* sink) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t stride = 23040;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  if (idx >= 30) return;
+  const char* srcA = base + (size_t)(xcd * 6 + idx / 5) * panel_bytes, *srcW = base + (size_t)(48 + idx % 5) * panel_bytes;
+  const unsigned lane_off = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+  floatx4 acc[6][7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const unsigned fr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (lane & 15) * 128 + ((((unsigned)lane >> 4) ^ (((unsigned)lane & 15) >> 1)) << 4);
+  auto rd = [&](unsigned addr) { half8 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; };
+  half8 fa[2][6], fb[2][7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fa[0][i] = rd(fr + ((wave >> 1) * 6 + i) * 2048);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) fb[0][j] = rd(fr + (12 + (wave & 1) * 7 + j) * 2048);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int cur = 0, b3 = 0;
+  for (int t = 0; t < ktiles; ++t) {
+    char* dst = smem + b3 * 53248 + wave * 1024;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned buf = (unsigned)b3 * 53248u;
+      const int nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fa[nxt][i] = rd(fr + buf + ((wave >> 1) * 6 + i) * 2048 + (h ? 0 : 64));
+#pragma unroll
+      for (int j = 0; j < 7; ++j) fb[nxt][j] = rd(fr + buf + (12 + (wave & 1) * 7 + j) * 2048 + (h ? 0 : 64));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int slot = h * 7 + i + (i == 5 && h == 0 ? 0 : 0);        // 7 slots in the first half (the 7th below), 6 in the second
+        if (slot < 13) {
+          const unsigned row = (unsigned)(slot * 32 + wave * 8);
+          const unsigned off = (slot < 6 ? row : row - 192) * (unsigned)stride + (unsigned)(t % 180) * 128 + lane_off;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(slot < 6 ? srcA : srcW), 0, (int)0x80000000, 0x00020000), (lptr)(dst + slot * 4096), 16, (int)off, 0, 0, 0);
+        }
+        if (h == 0 && i == 5) {
+          const unsigned row = (unsigned)(6 * 32 + wave * 8);
+          const unsigned off = (row - 192) * (unsigned)stride + (unsigned)(t % 180) * 128 + lane_off;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)srcW, 0, (int)0x80000000, 0x00020000), (lptr)(dst + 6 * 4096), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    b3 = b3 == 2 ? 0 : b3 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s += acc[i][j][0] + acc[i][j][3];
+  if (s == 12345.f) sink[blockIdx.x] = s;
+}
+
+static float run_fused_small(const char* buf, size_t panel, int ktiles, float* sink) {
+  hipFuncSetAttribute((const void*)fused_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  fused_small_kernel<<<256, 256, 156 * 1024>>>(buf, panel, 20, sink);
+  hipDeviceSynchronize();
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    fused_small_kernel<<<256, 256, 156 * 1024>>>(buf, panel, ktiles, sink);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
@@ -235,7 +326,13 @@ int main() {
     const float m = run_fused<3>(buf, panel, ktiles, sink), d = run_fused<2>(buf, panel, ktiles, sink), b = run_fused<1>(buf, panel, ktiles, sink);
     printf("%-28s %10.1f %10.1f %10.1f   both / max = %.2f, both / sum = %.2f   (ONE wave per SIMD issuing the MFMAs and the DMA, operand panels of a 12288 x 1280 x 11520 GEMM)\n",
            "fused, GEMM operand panels", m, d, b, b / (m > d ? m : d), b / (m + d));
-    printf("%-28s %10s %10s %10.1f   (the same with the fragment reads of a 128 x 128 wave tile, 64 accumulator tiles, a barrier per K-tile)\n", "fused + fragment reads", "", "", run_fused_reads(buf, panel, ktiles, sink));
+    printf("%-28s %10s %10s %10.1f   (the same with the fragment reads of a 128 x 128 wave tile, 64 accumulator tiles, a barrier per K-tile; requests two K-tiles ahead)\n", "fused + fragment reads", "", "", run_fused_reads<0>(buf, panel, ktiles, sink));
+    {
+      const float ts = run_fused_small(buf, panel, ktiles, sink);
+      printf("%-28s %10s %10s %10.1f   (192 x 224 tile, THREE K-tile buffers, requests two K-tiles ahead: %.0f TFLOP/s per 240 CUs against %.0f for the 256 x 256 forms above at 232 / 280 us)\n", "fused small tile", "", "",
+             ts, 240.0 * 192 * 224 * 64 * 2 * ktiles / (ts * 1e-6) / 1e12, 240.0 * 256 * 256 * 64 * 2 * ktiles / 232e-6 / 1e12);
+    }
+    printf("%-28s %10s %10s %10.1f   (what TWO K-tile buffers allow: requests in the second half of an iteration, waited for in the middle of the next)\n", "fused + reads, 2 buffers", "", "", run_fused_reads<1>(buf, panel, ktiles, sink));
   }
   printf("%s\n", hipGetLastError() == hipSuccess ? "ok" : "ERR");
   return 0;
