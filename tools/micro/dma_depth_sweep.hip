@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(512, 2) sweep_kernel(const char* base, size_t 
   if (mode == 2 || mode == 5) srcW = srcA + 128 * stride * 0;   // activation panels only (both halves of a K-tile from the m-panel: rows 0-255 twice)
   if (mode == 3) srcA = srcW;                        // weight panels only
   const unsigned rot = mode == 4 ? (unsigned)(idx % 5 + idx / 5) : 0u;   // the sharers of a panel one K-tile apart
-  const unsigned lane_off = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+  unsigned lane_off = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+  if (mode == 7) lane_off = (unsigned)((lane >> 2) * stride + (lane & 3) * 16);      // 64-byte row segments (a K-tile of 32): 16 rows per instruction
   // a step = DEPTH instructions of this wave; the waves of a CU cover rows [wave * DEPTH * 8, ...) of the 256-row panel slab, wrapping
   char* ring = smem + wave * (2 * DEPTH * 1024);
   for (int s = 0; s < steps; ++s) {
@@ -34,8 +35,9 @@ __global__ void __launch_bounds__(512, 2) sweep_kernel(const char* base, size_t 
     for (int i = 0; i < DEPTH; ++i) {
       const unsigned blk = (unsigned)((s * NW + wave) * DEPTH + i);
       // 64 instructions = one K-tile: the 256 activation rows, then the 256 weight rows, at k position blk / 64 (180 positions, each line once)
-      const unsigned row = (blk * 8) & 255, kofs = (((blk >> 6) + rot) % 180) * 128;
-      const char* src = (blk & 32) ? srcW : srcA;
+      unsigned row = (blk * 8) & 255, kofs = (((blk >> 6) + rot) % 180) * 128;
+      if (mode == 7) { row = (blk * 16) & 255; kofs = ((blk >> 5) % 360) * 64; }        // 32 instructions = one K-tile of 32: 256 + 256 rows x 64 bytes
+      const char* src = (mode == 7 ? (blk & 16) : (blk & 32)) ? srcW : srcA;
       unsigned off = row * (unsigned)stride + kofs + lane_off;
       if (mode >= 5 && (mode == 5 || !(blk & 32))) off = (kofs >> 7) * 32768u + row * 128u + (unsigned)lane * 16u;     // K-tile-blocked panel: a K-tile's 256 rows x 128 bytes are contiguous
       __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0x80000000, 0x00020000), (lptr)(dst + i * 1024), 16, (int)off, 0, 0, 0);
@@ -67,8 +69,9 @@ __global__ void __launch_bounds__(512, 2) pp_like_kernel(const char* base, size_
     for (int i = 0; i < 2; ++i) {
       const unsigned blk = (unsigned)((s * 8 + wave) * 2 + i);
       // 64 instructions = one K-tile: the 256 activation rows, then the 256 weight rows, at k position blk / 64 (180 positions, each line once)
-      const unsigned row = (blk * 8) & 255, kofs = (((blk >> 6) + rot) % 180) * 128;
-      const char* src = (blk & 32) ? srcW : srcA;
+      unsigned row = (blk * 8) & 255, kofs = (((blk >> 6) + rot) % 180) * 128;
+      if (mode == 7) { row = (blk * 16) & 255; kofs = ((blk >> 5) % 360) * 64; }        // 32 instructions = one K-tile of 32: 256 + 256 rows x 64 bytes
+      const char* src = (mode == 7 ? (blk & 16) : (blk & 32)) ? srcW : srcA;
       unsigned off = row * (unsigned)stride + kofs + lane_off;
       if (mode >= 5 && (mode == 5 || !(blk & 32))) off = (kofs >> 7) * 32768u + row * 128u + (unsigned)lane * 16u;     // K-tile-blocked panel: a K-tile's 256 rows x 128 bytes are contiguous
       __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0x80000000, 0x00020000), (lptr)(dst + i * 1024), 16, (int)off, 0, 0, 0);
@@ -97,7 +100,7 @@ static void run_pp(const char* buf, size_t panel_bytes, int mode, int* sink) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
-  printf("%-7s pp-like: 2 instructions per wave and phase, vmcnt(%2d), %d barriers per phase  %8.1f us  %6.1f B/clk/CU   %s\n", mode == 0 ? "shared" : mode == 1 ? "panels" : mode == 2 ? "A only" : mode == 3 ? "W only" : mode == 4 ? "rotated" : mode == 5 ? "A blk" : "pan blk", KEEP, NBAR, best * 1e3,
+  printf("%-7s pp-like: 2 instructions per wave and phase, vmcnt(%2d), %d barriers per phase  %8.1f us  %6.1f B/clk/CU   %s\n", mode == 0 ? "shared" : mode == 1 ? "panels" : mode == 2 ? "A only" : mode == 3 ? "W only" : mode == 4 ? "rotated" : mode == 5 ? "A blk" : mode == 6 ? "pan blk" : "pan 64B", KEEP, NBAR, best * 1e3,
          (double)steps * 16 * 1024 / (best * 1e-3) / 2.4e9, hipGetLastError() == hipSuccess ? "" : "ERR");
 }
 
@@ -119,7 +122,7 @@ static void run(const char* buf, size_t panel_bytes, int mode, int* sink) {
     if (ms < best) best = ms;
   }
   const double bytes = (double)steps * NW * DEPTH * 1024;
-  printf("%-7s waves %d  in flight <= %3d KB/CU  %8.1f us  %6.1f B/clk/CU at 2.4 GHz   %s\n", mode == 0 ? "shared" : mode == 1 ? "panels" : mode == 2 ? "A only" : mode == 3 ? "W only" : mode == 4 ? "rotated" : mode == 5 ? "A blk" : "pan blk", NW, NW * 2 * DEPTH, best * 1e3, bytes / (best * 1e-3) / 2.4e9,
+  printf("%-7s waves %d  in flight <= %3d KB/CU  %8.1f us  %6.1f B/clk/CU at 2.4 GHz   %s\n", mode == 0 ? "shared" : mode == 1 ? "panels" : mode == 2 ? "A only" : mode == 3 ? "W only" : mode == 4 ? "rotated" : mode == 5 ? "A blk" : mode == 6 ? "pan blk" : "pan 64B", NW, NW * 2 * DEPTH, best * 1e3, bytes / (best * 1e-3) / 2.4e9,
          hipGetLastError() == hipSuccess ? "" : "ERR");
 }
 
@@ -128,8 +131,8 @@ int main() {
   char* buf; if (hipMalloc(&buf, panel * 53 + (1 << 20)) != hipSuccess) { printf("alloc failed\n"); return 1; }
   hipMemset(buf, 0, panel * 53 + (1 << 20));
   int* sink; hipMalloc(&sink, 4096);
-  const char* names[7] = {"shared", "panels", "A only", "W only", "rotated", "A only, K-tile-blocked layout", "panels, A K-tile-blocked"};
-  for (int mode = 0; mode <= 6; ++mode) {
+  const char* names[8] = {"shared", "panels", "A only", "W only", "rotated", "A only, K-tile-blocked layout", "panels, A K-tile-blocked", "panels, 64-byte row segments (K-tile 32)"};
+  for (int mode = 0; mode <= 7; ++mode) {
     printf("--- source: %s\n", names[mode]);
     if (mode <= 1) { run<4, 2>(buf, panel, mode, sink); run<4, 4>(buf, panel, mode, sink); run<4, 8>(buf, panel, mode, sink); run<4, 16>(buf, panel, mode, sink); run<8, 2>(buf, panel, mode, sink); }
     run<8, 4>(buf, panel, mode, sink); run<8, 8>(buf, panel, mode, sink);
