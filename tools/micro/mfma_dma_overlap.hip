@@ -13,6 +13,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lptr;
 
+__global__ void fill_random(_Float16* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)(i >> 13); h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    p[i] = (_Float16)((float)(h & 0xffff) * (2.f / 65536.f) - 1.f);
+  }
+}
+
 template <int MODE>   // 1 = MFMA waves only, 2 = DMA waves only, 3 = both
 __global__ void __launch_bounds__(512, 2) overlap_kernel(const char* base, size_t region, int priv, int ktiles, float* sink) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -313,6 +320,12 @@ int main() {
   const size_t region = (size_t)12 << 20;     // 12 MB: 512 rows x 23040 bytes; private mode: 256 x 12 MB = 3 GB
   char* buf; if (hipMalloc(&buf, region * 256) != hipSuccess) { printf("alloc failed\n"); return 1; }
   hipMemset(buf, 0, region * 256);
+  if (getenv("OVERLAP_RANDOM")) {      // uniform fp16 in [-1, 1): zero operands flatter the matrix pipe's power draw (and with it the clock)
+    const size_t nh = region * 256 / 2;
+    fill_random<<<4096, 256>>>((_Float16*)buf, nh);
+    hipDeviceSynchronize();
+    printf("operands: uniform random fp16 in [-1, 1)\n");
+  }
   float* sink; hipMalloc(&sink, 4096);
   const int ktiles = 180;
   printf("%-28s %10s %10s %10s   (us, 180 K-tiles: 23040 MFMAs per MFMA wave = 2048 cycles per K-tile, 64 KB DMA per CU per K-tile)\n", "source", "MFMA", "DMA", "both");
