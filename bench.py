@@ -207,6 +207,9 @@ def main():
         return ((fw - cached) * UNET_GFLOP + cached * (UNET_GFLOP - TEXT_KV_GFLOP) + c["text_kv_rows"] * TEXT_KV_GFLOP) * 1e9 + \
             c["vae_encodes"] * VAE_ENC_TFLOP * 1e12 + c["vae_decodes"] * VAE_DEC_TFLOP * 1e12
 
+    def per_image_flops_faithful():
+        return executed_flops(ctr) / max(1, args.steps)
+
     # per-kernel-class roofline: one more full edit with every launch bracketed by HIP events (rank 0, outside the timed region)
     roofline, classes = None, None
     if rank == 0:
@@ -251,8 +254,9 @@ def main():
 
     # the two loops of one more edit timed on their own (rank 0, outside the timed region): the 50 one-row DDIM-inversion forwards and the
     # 50 twelve-row lock-step steps of the dual-branch loop north_star's 40 % target is stated on (models/p2p/p2p_guidance_forward.py:135-173)
-    phases = None
-    if rank == 0 and args.schedule == "lockstep":
+    def loop_phases(run, n_img):
+        """`run()` once more with a device synchronisation around pnpi_ddim_invert and pnpi_direct_edit (host wall clock): the n_img-row
+        inversion forwards and the 12 n_img-row lock-step steps of the dual-branch loop timed on their own"""
         marks = {}
 
         def timed(name, fn):
@@ -270,21 +274,32 @@ def main():
         try:
             torch.cuda.synchronize()
             t_all = time.perf_counter()
-            one_edit(999)
+            run()
             torch.cuda.synchronize()
             t_all = time.perf_counter() - t_all
         finally:
             eng.ddim_invert, eng.direct_edit = orig_inv, orig_edit
-        if "invert" in marks and "lockstep" in marks:
-            n = args.ddim_steps
-            loop_flop = n * 12 * (UNET_GFLOP - TEXT_KV_GFLOP) * 1e9 + 12 * TEXT_KV_GFLOP * 1e9      # text K / V projected once per loop
-            phases = {"ddim_inversion_ms": marks["invert"] * 1e3, "one_row_forward_ms": marks["invert"] * 1e3 / n,
-                      "lockstep_loop_ms": marks["lockstep"] * 1e3, "twelve_row_step_ms": marks["lockstep"] * 1e3 / n,
-                      "lockstep_loop_tflops": loop_flop / marks["lockstep"] / 1e12,
-                      "lockstep_loop_mfma_frac": loop_flop / marks["lockstep"] / 1e12 / MFMA_PEAK_TFLOPS,
-                      "rest_ms": (t_all - marks["invert"] - marks["lockstep"]) * 1e3,
-                      "note": "one more edit with a device synchronisation around pnpi_ddim_invert and pnpi_direct_edit (host wall clock); "
-                              "rest = VAE encode / decodes, text encoder, controller tables, panel"}
+        if "invert" not in marks or "lockstep" not in marks:
+            return None
+        n = args.ddim_steps
+        rows = 12 * n_img
+        loop_flop = n * rows * (UNET_GFLOP - TEXT_KV_GFLOP) * 1e9 + rows * TEXT_KV_GFLOP * 1e9      # text K / V projected once per loop
+        return {"ddim_inversion_ms": marks["invert"] * 1e3, "inversion_rows": n_img, "inversion_forward_ms": marks["invert"] * 1e3 / n,
+                "lockstep_loop_ms": marks["lockstep"] * 1e3, "lockstep_rows": rows, "lockstep_step_ms": marks["lockstep"] * 1e3 / n,
+                "lockstep_loop_tflops": loop_flop / marks["lockstep"] / 1e12,
+                "lockstep_loop_mfma_frac": loop_flop / marks["lockstep"] / 1e12 / MFMA_PEAK_TFLOPS,
+                "rest_ms": (t_all - marks["invert"] - marks["lockstep"]) * 1e3,
+                "note": "one more run with a device synchronisation around pnpi_ddim_invert and pnpi_direct_edit (host wall clock); "
+                        "rest = VAE encode / decodes, text encoder, controller tables, panel"}
+
+    # the two loops of one more edit timed on their own (rank 0, outside the timed region): the 50 one-row DDIM-inversion forwards and the
+    # 50 twelve-row lock-step steps of the dual-branch loop north_star's 40 % target is stated on (models/p2p/p2p_guidance_forward.py:135-173)
+    phases = None
+    if rank == 0 and args.schedule == "lockstep":
+        phases = loop_phases(lambda: one_edit(999), 1)
+        if phases is not None:      # the names round 4's line used
+            phases["one_row_forward_ms"] = phases["inversion_forward_ms"]
+            phases["twelve_row_step_ms"] = phases["lockstep_step_ms"]
 
     # extra (never `value`): the pruned-equivalent schedule of SURVEY Note D, FLOPs from the library's counters
     pruned = None
@@ -373,7 +388,12 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dtb = float(tt.item())
         batched = {"images_per_launch_set_per_gpu": nb, "value": nb * world / dtb, "unit": "images/s", "ms_per_batch": dtb * 1e3,
-                   "note": "same faithful schedule per image; %d-row inversion launches, %d-row lock-step launches" % (nb, 12 * nb)}
+                   "whole_path_mfma_frac": nb * (per_image_flops_faithful() / dtb) / 1e12 / MFMA_PEAK_TFLOPS,
+                   "note": "BASELINE config 3's launch shape (batch = %d per GPU): same faithful schedule per image; %d-row inversion launches, "
+                           "%d-row lock-step launches" % (nb, nb, 12 * nb)}
+        if rank == 0:
+            # the same loop north_star's 40 % target is stated on, at config 3's batch: 50 steps of one 12 nb-row launch set
+            batched["phases"] = loop_phases(lambda: batch_edit(1), nb)
 
     # extra (never `value`): sweep throughput with the NEXT image's inversion on a second context / HIP stream under this image's
     # lock-step loop (P2PEditor.edit_stream_directinversion); same kernels, same panels
@@ -443,29 +463,34 @@ def main():
         if roofline is not None:
             roofline["source_sha16"] = sha
             tag = roofline["kernel"].replace(" ", "")           # igemm_pp_kernel<192,320,1,4,0>
-            pmc = os.path.join(prof, "round4_pmc_traffic_bench.json")
-            if not os.path.exists(pmc):
-                roofline["traffic_note"] = "no committed counter summary (profiles/round4_pmc_traffic_bench.json)"
+            rounds = ("round5", "round4")
+            cand = [os.path.join(prof, "%s_pmc_traffic_bench.json" % r) for r in rounds]
+            have = [(c_, json.load(open(c_))) for c_ in cand if os.path.exists(c_)]
+            match = [(c_, j_) for c_, j_ in have if j_.get("source_sha16") == sha]
+            if not have:
+                roofline["traffic_note"] = "no committed counter summary (profiles/round5_pmc_traffic_bench.json)"
+            elif not match:
+                roofline["traffic_note"] = "%s was measured on kernel sources %s, this tree is %s: not reported" % (
+                    os.path.relpath(have[0][0], os.path.dirname(prof)), have[0][1].get("source_sha16"), sha)
             else:
-                src_json = json.load(open(pmc))
-                if src_json.get("source_sha16") != sha:
-                    roofline["traffic_note"] = "profiles/round4_pmc_traffic_bench.json was measured on kernel sources %s, this tree is %s: not reported" % (
-                        src_json.get("source_sha16"), sha)
+                pmc, src_json = match[0]
+                rel_pmc = os.path.relpath(pmc, os.path.dirname(prof))
+                for name, v in src_json["kernels"].items():
+                    if v.get("template") == tag:
+                        roofline["traffic"] = v["traffic_bytes"]
+                        roofline["traffic_over_alg"] = v["traffic_bytes"] / roofline["alg_bytes_per_launch"]
+                        if "mfma_util" in v:
+                            roofline["mfma_busy"] = v["mfma_util"]
+                        roofline["traffic_source"] = "%s (same kernel sources, %s): %s" % (rel_pmc, sha, src_json.get("source"))
+                        break
                 else:
-                    for name, v in src_json["kernels"].items():
-                        if v.get("template") == tag:
-                            roofline["traffic"] = v["traffic_bytes"]
-                            roofline["traffic_over_alg"] = v["traffic_bytes"] / roofline["alg_bytes_per_launch"]
-                            if "mfma_util" in v:
-                                roofline["mfma_busy"] = v["mfma_util"]
-                            roofline["traffic_source"] = "profiles/round4_pmc_traffic_bench.json (same kernel sources, %s): %s" % (sha, src_json.get("source"))
-                            break
-                    else:
-                        roofline["traffic_note"] = "the dominant kernel %s has no entry in profiles/round4_pmc_traffic_bench.json" % tag
+                    roofline["traffic_note"] = "the dominant kernel %s has no entry in %s" % (tag, rel_pmc)
             # the rocprofv3 --kernel-trace --stats average of the same kernel under this command (committed summary + its source hash): the
             # HIP-event bracket above also carries the packet-processing gap in front of the kernel, which differs between boxes of the pool
-            stats_csv, meta = os.path.join(prof, "round4_bench_kernel_stats.csv"), os.path.join(prof, "round4_bench_kernel_stats.meta.json")
-            if os.path.exists(stats_csv) and os.path.exists(meta) and json.load(open(meta)).get("source_sha16") == sha:
+            for r in rounds:
+                stats_csv, meta = os.path.join(prof, "%s_bench_kernel_stats.csv" % r), os.path.join(prof, "%s_bench_kernel_stats.meta.json" % r)
+                if not (os.path.exists(stats_csv) and os.path.exists(meta) and json.load(open(meta)).get("source_sha16") == sha):
+                    continue
                 import csv
                 name, targs = tag.split("<")
                 want = "%d%sI" % (len(name), name) + "".join("Li%sE" % a for a in targs.rstrip(">").split(",")) + "E"
@@ -475,9 +500,10 @@ def main():
                         roofline["rocprof"] = {"avg_launch_us": us, "calls": int(row["Calls"]),
                                                "achieved": roofline["alg_flop_per_launch"] / us / 1e6,
                                                "frac": roofline["alg_flop_per_launch"] / us / 1e6 / MFMA_PEAK_TFLOPS,
-                                               "source": "profiles/round4_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `bench.py --steps 2 "
-                                                         "--warmup 1 --no-extras --no-cpu-baseline` (faithful edits only; same kernel sources, %s)" % sha}
+                                               "source": "profiles/%s_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `bench.py --steps 2 "
+                                                         "--warmup 1 --no-extras --no-cpu-baseline` (faithful edits only; same kernel sources, %s)" % (r, sha)}
                         break
+                break
         n_img = args.steps * world
         per_rank_flops = executed_flops(ctr)
         out = {

@@ -139,7 +139,9 @@ typedef struct {
 int pnpi_create(pnpi_ctx** out, const pnpi_model_config* cfg, int device, void* hip_stream, int max_unet_rows, int max_vae_images);
 /* A further context on the SAME packed weights (same device, same model configuration): own stream, workspaces and caches, the
  * parent's weight arena borrowed read-only instead of copied (several images in flight on one GPU: one 1.9 GB arena in the caches
- * instead of N).  The parent must outlive the child; reloading the parent's weights while children exist is the caller's error
+ * instead of N).  The arena is reference-counted: it is freed by the last pnpi_destroy among the parent and its children, in whatever
+ * order they are destroyed.  A failed pnpi_create / pnpi_create_shared leaves a context in *out that only pnpi_last_error and
+ * pnpi_destroy accept (call both).  Reloading the parent's weights while children exist is the caller's error
  * (call pnpi_mark_all_loaded on each child afterwards); pnpi_load_weights on a child fails with PNPI_ESTATE.  There is no
  * counterpart in the reference (one pipeline object per process, models/p2p_editor.py:18-25). */
 int pnpi_create_shared(pnpi_ctx** out, pnpi_ctx* parent, void* hip_stream, int max_unet_rows, int max_vae_images);

@@ -766,6 +766,12 @@ if __name__ == "__main__":
     if "masactrl_sd1" in which:
         # BASELINE config 5 at the benchmarked width: 4 steps, mutual self-attention from step 1 in transformer blocks 10..15
         masactrl(steps=4, start_step=1, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1")
+    if "null_text_sd1_5" in which:
+        # round 5: the same at 5 steps x 10 Adam iterations (about 25 CPU-minutes): drift of the fp16 reverse walk / Adam state over more steps
+        null_text(steps=5, cfg=SD1, seed=0, name="e2e_null_text_sd1_5")
+    if "masactrl_sd1_10" in which:
+        # round 5: 10 steps, mutual self-attention from step 3 (about 15 CPU-minutes)
+        masactrl(steps=10, start_step=3, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_10")
     if "masactrl_lists" in which:
         masactrl_lists()
     if "null_latent" in which or not sys.argv[1:]:

@@ -47,7 +47,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, ablations=False):
+    """ablations: also compile the kernel instances that leave out the MFMAs / the DMA / the fragment reads (tools/pp_ablate.py,
+    tools/profile_pp.sh, tuning igemm_vpp / igemm_sched / igemm_v128 = 11, 12, 15) -- not part of the product library."""
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -63,6 +65,8 @@ def build(force=False, verbose=True):
         extra = list(EXTRA.get(os.path.basename(s), []))
         if os.path.basename(s)[:-4] in os.environ.get("PNPI_VGPR_FORM", "").split(","):   # experiments: PNPI_VGPR_FORM=gemm
             extra += ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+        if ablations:
+            extra += ["-DPNPI_ABLATIONS=1"]
         cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -89,4 +93,4 @@ if __name__ == "__main__":
     if "--source-hash" in sys.argv:
         print(source_hash())
     else:
-        build(force="--force" in sys.argv)
+        build(force="--force" in sys.argv or "--ablations" in sys.argv, ablations="--ablations" in sys.argv)

@@ -137,8 +137,10 @@ static int create_impl(pnpi_ctx** out, const pnpi_model_config* cfg, int device,
   if (parent) {
     if (parent->warena.cap != wbytes) return fail(c, PNPI_ESTATE, "pnpi_create_shared: the parent's weight arena has another size");
     c->warena.base = parent->warena.base; c->warena_borrowed = true;
+    c->warena_ref = parent->warena_ref; c->warena_ref->refs.fetch_add(1);      // the arena lives until its last user is destroyed
   } else {
     CKH(hipMalloc((void**)&c->warena.base, wbytes));
+    c->warena_ref = new pnpi_ctx::ArenaRef{c->warena.base, {1}};
     CKH(hipMemsetAsync(c->warena.base, 0, wbytes, c->st));
   }
   c->warena.cap = wbytes; c->warena.reset(); c->warena.peak = 0;
@@ -248,7 +250,11 @@ static int create_impl(pnpi_ctx** out, const pnpi_model_config* cfg, int device,
 void pnpi_destroy(pnpi_ctx* c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->st);
-  void* bufs[] = {c->warena_borrowed ? nullptr : (void*)c->warena.base, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial, c->gn_bwd_ws,
+  // the weight arena is shared with the contexts pnpi_create_shared made from this one (or borrowed from the one this was made from):
+  // whoever is destroyed last frees it -- destroying the owner first does not pull the weights from under a running child
+  void* arena = nullptr;
+  if (c->warena_ref && c->warena_ref->refs.fetch_sub(1) == 1) { arena = c->warena_ref->base; delete c->warena_ref; }
+  void* bufs[] = {arena, c->persist.base, c->temp.base, c->ctrl_arena.base, c->splitk_ws, c->gn_partial, c->gn_bwd_ws,
                   c->temb_table, c->temb_h, c->temb_emb, c->bias_scratch, c->bias_tab, c->tkv.base, c->rows_ident};
   for (void* b : bufs) (void)hipFree(b);
   if (c->tape) {
@@ -956,6 +962,7 @@ int pnpi_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gn_inline_rows")) { norm_set_tuning_gn_inline_rows(value); return 0; }
   if (!strcmp(key, "attn_vt_perm")) { g_vt_perm = value; return 0; }
   if (!strcmp(key, "attn_aug")) { g_attn_aug = value; return 0; }
+  if (!strcmp(key, "gn_slab")) { g_gn_slab = value; return 0; }
   if (!strcmp(key, "op_attention_aug")) { g_op_attention_aug = value; return 0; }
   if (!strcmp(key, "op_attention_vt_perm")) { g_op_attention_vt_perm = value; return 0; }
   if (!strcmp(key, "attn_bwd_flash")) { g_attn_bwd_flash = value; return 0; }

@@ -226,7 +226,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 //     log2 domain and already shifted by the running maximum: P = exp2(S') with no per-element fma.  m_run is kept exactly representable
 //     in fp16 (it is a reference point, not the true maximum: the deferred-rescale threshold of 8 covers the rounding);
 //   * V^T row 40 is all ones, so O^T row 40 accumulates sum_k P -- with the same fp16-rounded P the numerator uses: no per-element add.
-// Same results to rounding (Q is rounded once more after the scaling); ~30 % fewer VALU cycles per tile.
+// Same results to rounding (Q is rounded once more after the fp32 scaling: independent half-ulp errors, no bias); ~30 % fewer VALU cycles per tile.
 template <bool VPERM, int KSQ = 4, bool AUG = false>
 __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   constexpr int DP = 64, KS = 4, OT = 2;
@@ -255,9 +255,12 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   }
   const float c = p.scale * 1.44269504088896340736f;
   if (AUG) {
-    const half_t ch = (half_t)c;
+    // S in the log2 domain straight from the MFMA.  The factor is applied in fp32 and the product rounded once: an fp16 factor
+    // (0.228149 for 0.22811 at d = 40) would put a correlated +1.7e-4 relative error -- a temperature bias -- on every logit
 #pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) qf[ks] = qf[ks] * ch;          // S in the log2 domain straight from the MFMA
+    for (int ks = 0; ks < KSQ; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * c);
   }
   floatx16 O[OT];
 #pragma unroll

@@ -479,13 +479,35 @@ int igemm_table_lookup(int M, int N, int K, int ks, int* cfg, int* split, int* e
   return how;
 }
 // cfg 6 = 256x320, 7 = 256x256 (8 waves, 128-byte rows, two stages, one block per CU); 8-11: K-parallel wave groups; 12 = 64x320;
-// 13 = 128x128 with a two-stage ring; 14 / 15 = 128x128 / 128x256 with 128-byte rows: reached through the table or force_cfg
+// 13 = 128x128 with a two-stage ring; 14 / 15 = 128x128 / 128x256 with 128-byte rows; 18 = 128x128, 128-byte rows, three stages:
+// reached through the table or force_cfg
 
 // product tile configurations with one k-group: compiler-scheduled main loop, or (tuning "igemm_sched") the hand-scheduled one
+#ifdef PNPI_ABLATIONS
 #define LDMA(...) (g_sched == 1 ? launch_dma<__VA_ARGS__, 2, 4>(p, grid, st, g_zero_page) : g_sched == 2 ? launch_dma<__VA_ARGS__, 2, 5>(p, grid, st, g_zero_page) : launch_dma<__VA_ARGS__>(p, grid, st, g_zero_page))
+#else
+#define LDMA(...) launch_dma<__VA_ARGS__>(p, grid, st, g_zero_page)
+#endif
 #define LDMA0(...) launch_dma<__VA_ARGS__>(p, grid, st, g_zero_page)
+// Can the 8-wave ping-pong kernel (cfg 16 = 256 x 256, 17 = 192 x 320) take this launch?  It has no scalar epilogue: a launch either takes
+// the LDS epilogue (whole tiles plain or transposed, 16-byte rows, 16-byte aligned bias) or writes split-K slabs; its DMA addresses are
+// 32-bit byte offsets under a 2 GiB buffer descriptor (operands beyond that stay on the 64-bit-pointer kernels); batched launches stay
+// on the 4-wave kernels.
+static bool pp_eligible(const GemmP& p, int cfg, int split, bool dma_ok) {
+  const int bn_pp = cfg == 17 ? 320 : 256;
+  const bool vt_none_ = p.vt_col0 >= p.N;
+  const bool vt_lds_ = !vt_none_ && p.outT && !p.vt_f32 && p.vt_col0 % bn_pp == 0 && p.rows_per_batch % 8 == 0 && p.vt_ld % 8 == 0 && p.M % 8 == 0 && !p.res &&
+                       !p.geglu && g_vt_lds;
+  const bool epi_ok = (vt_none_ || vt_lds_) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) &&
+                      (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.vt_perm16 || p.rows_per_batch % 16 == 0);
+  const double lim = 2147483648.0 - 1048576.0;
+  const bool off32_ok = 2.0 * p.B * p.H * p.W * (double)(p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) < lim && 2.0 * (double)p.N * p.ldw < lim;
+  return dma_ok && off32_ok && !(split == 1 && !epi_ok) && !(split > 1 && p.N % 4 != 0) && p.nbatch <= 1;
+}
+
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg, int force_split, int* cfg_used,
-                 int* stats_tile_rows) {
+                 int* stats_tile_rows, GemmP* deferred) {
+  if (deferred) deferred->splitk = 1;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -2;
   const int Cin = p.C1 + p.C2;
   if ((Cin & 7) || (p.K & 7) || (p.C1 & 7) || (p.ldw & 7) || (p.ldx1 & 7) || (p.C2 && (p.ldx2 & 7))) return -3;
@@ -507,7 +529,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
         const bool vt_ok = p.vt_col0 >= p.N || p.vt_col0 % ebn == 0;
         const bool pp_masked = (e.cfg == 16 || e.cfg == 17) && ((g_pp_only_n > 0 && p.N != g_pp_only_n) || (g_pp_only_k > 0 && p.K != g_pp_only_k) || (g_pp_only_m > 0 && p.M != g_pp_only_m) ||
                                                                  g_pp_only_n < 0);
-        if (split_ok && vt_ok && !pp_masked && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14)) { cfg = e.cfg; split = e.split; }
+        // a ping-pong entry (tile and split tuned together) applies only to a launch that kernel can take: otherwise the cost model
+        // picks tile AND split for the 4-wave kernels (not the entry's split on a 128 x 128 tile)
+        const bool pp_ok = !(e.cfg == 16 || e.cfg == 17) || pp_eligible(p, e.cfg, e.split, dma_ok);
+        if (split_ok && vt_ok && !pp_masked && pp_ok && (g_wide || e.cfg < 4 || e.cfg == 13 || e.cfg == 14 || e.cfg == 18)) { cfg = e.cfg; split = e.split; }
     }
   }
   if (cfg < 0) {
@@ -556,23 +581,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     if (split > nchunks) split = nchunks;
     if (ws == nullptr || (size_t)split * p.M * p.N * sizeof(float) > ws_bytes || p.geglu || cfg == 3) split = 1;
   }
-  if (cfg == 16 || cfg == 17) {
-    // the ping-pong kernel has no scalar epilogue: a launch either takes the LDS epilogue (whole tiles plain or transposed, 16-byte rows,
-    // 16-byte aligned bias) or writes split-K slabs; anything else goes to the 128 x 128 kernel
-    const int bn_pp = cfg == 17 ? 320 : 256;
-    const bool vt_none_ = p.vt_col0 >= p.N;
-    const bool vt_lds_ = !vt_none_ && p.outT && !p.vt_f32 && p.vt_col0 % bn_pp == 0 && p.rows_per_batch % 8 == 0 && p.vt_ld % 8 == 0 && p.M % 8 == 0 && !p.res &&
-                         !p.geglu && g_vt_lds;
-    const bool epi_ok = (vt_none_ || vt_lds_) && (p.N % 8 == 0) && (p.vt_col0 == 0 || p.ldo % 8 == 0) && (!p.res || p.ldres % 8 == 0) &&
-                        (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.vt_perm16 || p.rows_per_batch % 16 == 0);
-    // its DMA addresses are 32-bit byte offsets under a 2 GiB buffer descriptor: operands beyond that stay on the 64-bit-pointer kernels
-    const double lim = 2147483648.0 - 1048576.0;
-    const bool off32_ok = 2.0 * p.B * p.H * p.W * (double)(p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) < lim && 2.0 * (double)p.N * p.ldw < lim;
-    if (!dma_ok || !off32_ok || (split == 1 && !epi_ok) || (split > 1 && p.N % 4 != 0) || p.nbatch > 1) cfg = 0;     // (batched launches stay on the 4-wave kernels)
-  }
+  if ((cfg == 16 || cfg == 17) && !pp_eligible(p, cfg, split, dma_ok)) cfg = 0;     // forced configurations (tests, sweeps): the 128 x 128 kernel instead
   const bool c64 = cfg == 1 || cfg == 8 || cfg == 11 || cfg == 12, c256m = cfg == 3 || cfg == 6 || cfg == 7 || cfg == 16;
   const bool cpp = cfg == 16 || cfg == 17;      // the 8-wave ping-pong kernel: 16 = 256 x 256, 17 = 192 x 320
-  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12 || cfg >= 15) ? 9 : (c64 ? 1 : 0));
+  if (cfg_used) *cfg_used = split > 1 ? 2 : (((cfg >= 4 && cfg <= 7) || cfg == 12 || (cfg >= 15 && cfg <= 17)) ? 9 : (c64 ? 1 : 0));
   p.splitk = split;
   p.kchunks_per_split = (nchunks + split - 1) / split;
   g_last_cfg = cfg; g_last_split = split;
@@ -619,14 +631,18 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     else switch (g_var320) {
       case 0: r = LDMA0(128, 320, 32, 3); break;       // 84 KB ring = whole-tile epilogue, 1 block / CU
       case 2: r = LDMA0(128, 320, 64, 2); break;       // 128-byte rows, 112 KB, 1 block / CU
+#ifdef PNPI_ABLATIONS
       case 11: r = launch_dma<128, 320, 32, 2, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
       case 12: r = launch_dma<128, 320, 32, 2, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
+#endif
       default: r = LDMA(128, 320, 32, 2); break;      // 56 KB ring, two-pass epilogue, 2 blocks / CU
     }
   } else if (cfg == 12) {
     r = LDMA0(64, 320, 32, 2);             // 64 x 320: 768 tiles on the 12-row 64 x 64 level = 3 per CU
   } else if (cfg == 13) {
     r = LDMA(128, 128, 32, 2);            // 32 KB ring (two-pass epilogue): 4 blocks / CU for the short-K layers
+  } else if (cfg == 18) {
+    r = LDMA0(128, 128, 64, 3);           // 128-byte rows, three stages (96 KB, 1 block / CU): the one-wave launches of the 16 x 16 level
   } else if (cfg == 14) {
     r = LDMA(128, 128, 64, 2);            // 128-byte rows, half the barriers per k: 64 KB, 2 blocks / CU
   } else if (cfg == 15) {
@@ -642,6 +658,7 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
   } else if (cfg == 16 || cfg == 17) {
     p.k_order = (g_tapin && p.ksize == 3) ? 1 : 0;
 #define LPP(...) (cfg == 16 ? launch_pp<256, 256, 2, 4, __VA_ARGS__>(p, grid, st, g_zero_page) : launch_pp<192, 320, 1, 4, __VA_ARGS__>(p, grid, st, g_zero_page))
+#ifdef PNPI_ABLATIONS      // `python -m pnpinversion_amd.build --ablations`: tools/pp_ablate.py, tools/profile_pp.sh
     switch (g_varpp) {
       case 1: r = LPP(1); break;     // ablations: no MFMAs
       case 2: r = LPP(2); break;     // no DMA
@@ -649,6 +666,10 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
       case 4: r = LPP(4); break;     // MFMAs only
       default: r = LPP(0); break;
     }
+#else
+    if (g_varpp) return -10;         // the ablation instances are not in this build
+    r = LPP(0);
+#endif
 #undef LPP
   } else if (cfg == 6) {
     r = launch_dma<256, 320, 64, 2, 4>(p, grid, st, g_zero_page);
@@ -674,9 +695,11 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
       case 3: r = LDMA0(128, 128, 32, 4); break;
       case 4: r = LDMA(128, 128, 32, 2); break;
       case 8: r = LDMA0(128, 128, 32, 8); break;       // 128 KB ring: sparse launches
+#ifdef PNPI_ABLATIONS
       case 11: r = launch_dma<128, 128, 32, 3, 2, 1>(p, grid, st, g_zero_page); break;   // ablation: DMA only
       case 12: r = launch_dma<128, 128, 32, 3, 2, 2>(p, grid, st, g_zero_page); break;   // ablation: compute only
       case 15: r = launch_dma<128, 128, 32, 3, 2, 3>(p, grid, st, g_zero_page); break;   // ablation: activation loads for tap 0 only
+#endif
       default: r = LDMA(128, 128, 64, 2); break;
     }
   } else {
@@ -698,8 +721,21 @@ int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_
     if (blocks > 2048) blocks = 2048;
     const bool vec = p.N % 4 == 0 && p.vt_col0 >= p.N && p.ldo % 4 == 0 && (!p.res || p.ldres % 4 == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                      ((uintptr_t)p.out & 7) == 0 && (!p.res || ((uintptr_t)p.res & 7) == 0) && ((uintptr_t)ws & 15) == 0;
+    // a caller that asked for it gets the slabs instead of the combine launch (alpha == 1: `v * 1 + bias` has the same bits fused or
+    // not): it either runs launch_splitk_reduce itself or hands the slabs to a consumer that sums them in the same order (GroupNorm)
+    if (vec && deferred && p.alpha == 1.f) { *deferred = p; return (int)hipGetLastError(); }
     if (vec) splitk_reduce_vec_kernel<<<blocks, 256, 0, st>>>(p);
     else splitk_reduce_kernel<<<blocks, 256, 0, st>>>(p);
   }
+  return (int)hipGetLastError();
+}
+
+// the combine of a launch_igemm call that deferred it (`p` as returned through `deferred`: splitk > 1, the vectorised layout)
+int launch_splitk_reduce(const GemmP& p, hipStream_t st) {
+  if (p.splitk <= 1 || !p.slab) return -2;
+  const size_t total = (size_t)p.M * (p.N / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  splitk_reduce_vec_kernel<<<blocks, 256, 0, st>>>(p);
   return (int)hipGetLastError();
 }

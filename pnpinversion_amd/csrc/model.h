@@ -1,5 +1,6 @@
 // Host-side model description for libpnpi: weight slots, SD-1.x UNet / VAE graphs, workspace planning.
 #pragma once
+#include <atomic>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -180,7 +181,9 @@ struct pnpi_ctx {
   Bump warena, persist, temp, ctrl_arena;
   struct AugBias { float* p; int heads, Dp, dh; };
   std::vector<AugBias> aug_biases;                  // the b_qkv_aug vectors of this build (filled after the arena exists)
-  bool warena_borrowed = false;                     // pnpi_create_shared: warena.base is the parent's (never freed / written here)
+  bool warena_borrowed = false;                     // pnpi_create_shared: warena.base is the parent's (never written here)
+  struct ArenaRef { void* base; std::atomic<int> refs; };
+  ArenaRef* warena_ref = nullptr;                   // shared by the owner and every context that borrows the arena: the last pnpi_destroy frees it
   float* splitk_ws; size_t splitk_bytes;
   float* gn_partial;
   float* temb_table;      // [n_train][C0] fp32 sinusoid table
@@ -211,4 +214,8 @@ struct pnpi_ctx {
   bool prof_on = false;
   std::vector<ProfRec> prof;
   Tape* tape = nullptr;          // non-null while a forward is being recorded for a backward pass
+  // A split-K launch of the UNet forward whose combine has not run yet (api_graph.inc: op_conv defers it, the next op either is the
+  // GroupNorm that reads the tensor -- it then sums the slabs itself -- or runs the combine first).  pend_keep: somebody besides that
+  // GroupNorm reads the fp16 tensor (residual / skip connection), so the fused kernel must also store it.
+  GemmP pend; bool pend_on = false, pend_keep = true, defer_ok = false;
 };

@@ -160,11 +160,17 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict_
 // Small feature maps (16x16 / 8x8 levels): one block per (batch item, group) does everything in ONE launch -- the group's
 // HW x cpg slice is parked in LDS between the statistics pass and the apply pass.  These tensors are < 1 MB; three dependent
 // launches were pure latency.
-static constexpr int GN_SMALL_ELEMS = 24576;   // largest (sample, group) slice of gn_small_kernel: its registers hold the slice
-template <int NT>
+// largest (sample, group) slice of gn_small_kernel: its registers hold the slice.  (Round 5: raising it to the 64 x 64 level's 40 960
+// elements for launches of fewer than 256 blocks -- one launch instead of two or three on the one-row forwards -- measured neutral,
+// 4.556 vs 4.548 ms per one-row forward: not kept.)
+static constexpr int GN_SMALL_ELEMS = 24576;
+// SLAB: the first source is not a tensor yet but the split-K slabs of the GEMM that produces it (GnSlab, ops.h): the block sums the
+// slabs of its slice in slab order, adds bias and residual and rounds to fp16 -- operation for operation what splitk_reduce_vec_kernel
+// does, so the statistics and the output are bit-identical to the two-launch path -- and stores that tensor only if somebody else reads it.
+template <int NT, bool SLAB = false>
 __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2, int C1, int C2,
                                                        int HW, int G, float eps, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int silu, half_t* __restrict__ out) {
+                                                       const float* __restrict__ beta, int silu, half_t* __restrict__ out, GnSlab sl = GnSlab()) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   half4* s_x = reinterpret_cast<half4*>(smem_raw);     // [HW * cpg / 4]
   __shared__ float s_s[NT / 64], s_q[NT / 64];
@@ -187,15 +193,55 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(const half_t* __restrict__
   // thread in a kernel that is pure latency (a loop around batches makes the compiler drain the counter at the loop header).
   constexpr int MAXV = GN_SMALL_ELEMS / 4 / NT;
   half4 val[MAXV];
+  if constexpr (!SLAB) {
 #pragma unroll
-  for (int u = 0; u < MAXV; ++u) {
-    const int idx = min(tid + u * NT, nvec - 1);
-    const int pix = idx / v4, v = idx - pix * v4;
-    const int c = g * cpg + 4 * v;
-    const bool first = c < C1;            // selects on the operands, one address computation: no divergent control flow between the loads
-    const half_t* sb = first ? x1 : x2;
-    const int ld = first ? C1 : C2, cc = first ? c : c - C1;
-    val[u] = *reinterpret_cast<const half4*>(sb + ((size_t)b * HW + pix) * ld + cc);
+    for (int u = 0; u < MAXV; ++u) {
+      const int idx = min(tid + u * NT, nvec - 1);
+      const int pix = idx / v4, v = idx - pix * v4;
+      const int c = g * cpg + 4 * v;
+      const bool first = c < C1;            // selects on the operands, one address computation: no divergent control flow between the loads
+      const half_t* sb = first ? x1 : x2;
+      const int ld = first ? C1 : C2, cc = first ? c : c - C1;
+      val[u] = *reinterpret_cast<const half4*>(sb + ((size_t)b * HW + pix) * ld + cc);
+    }
+  } else {
+    floatx4 acc[MAXV];
+    size_t eoff[MAXV];                      // element offset of the vector in [M][C1] (slab, bias-free sum_out; ldo == C1)
+    bool isl[MAXV];
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      const int idx = min(tid + u * NT, nvec - 1);
+      const int pix = idx / v4, v = idx - pix * v4;
+      const int c = g * cpg + 4 * v;
+      isl[u] = c < C1;
+      eoff[u] = ((size_t)b * HW + pix) * C1 + (isl[u] ? c : 0);
+      acc[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (!isl[u]) val[u] = *reinterpret_cast<const half4*>(x2 + ((size_t)b * HW + pix) * C2 + (c - C1));
+    }
+#pragma unroll 2
+    for (int z = 0; z < sl.splitk; ++z) {
+      const float* sz = sl.slab + (size_t)z * sl.stride;
+#pragma unroll
+      for (int u = 0; u < MAXV; ++u)
+        if (isl[u]) acc[u] += *reinterpret_cast<const floatx4*>(sz + eoff[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      if (!isl[u]) continue;
+      const int idx = min(tid + u * NT, nvec - 1);
+      const int pix = idx / v4, v = idx - pix * v4;
+      const int c = g * cpg + 4 * v;
+      floatx4 w = acc[u];
+      if (sl.bias) w += *reinterpret_cast<const floatx4*>(sl.bias + c);
+      if (sl.res) {
+        const half4 r4 = *reinterpret_cast<const half4*>(sl.res + ((size_t)b * HW + pix) * sl.ldres + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] += (float)r4[j];
+      }
+      const half4 h = {(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
+      val[u] = h;
+      if (sl.sum_out && tid + u * NT < nvec) *reinterpret_cast<half4*>(sl.sum_out + eoff[u]) = h;
+    }
   }
 #pragma unroll
   for (int u = 0; u < MAXV; ++u) {
@@ -266,6 +312,24 @@ static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, i
     gn_small_kernel<1024><<<dim3(B, G), 1024, (size_t)HW * cpg * sizeof(half_t) + (size_t)cpg * 8 + 16, st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
   else
     gn_small_kernel<256><<<dim3(B, G), 256, (size_t)HW * cpg * sizeof(half_t) + (size_t)cpg * 8 + 16, st>>>(x1, x2, C1, C2, HW, G, eps, gamma, beta, silu, out);
+  return (int)hipGetLastError();
+}
+
+bool groupnorm_slab_ok(int C1, int C2, int HW, int G) { return C1 > 0 && (C2 == 0 || C2 % 4 == 0) && gn_small_ok(C1, C2, HW, G); }
+int launch_groupnorm_slab(const GnSlab& sl, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                          const float* beta, int silu, half_t* out, hipStream_t st) {
+  const int C = C1 + C2;
+  if ((C & 7) || (C1 & 7) || C % G || G > 64 || !groupnorm_slab_ok(C1, C2, HW, G) || sl.splitk < 2 || !sl.slab) return -3;
+  if (((uintptr_t)sl.slab & 15) || (sl.bias && ((uintptr_t)sl.bias & 15)) || (sl.res && (((uintptr_t)sl.res & 7) || (sl.ldres & 3))) ||
+      (sl.sum_out && ((uintptr_t)sl.sum_out & 7)) || (sl.stride & 3))
+    return -3;
+  const int cpg = C / G;
+  static DeviceOnce attr_once;
+  if (int r = once_per_device(attr_once, [&]() {
+        return (int)hipFuncSetAttribute((const void*)gn_small_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gn_small_max() * 2 + 8192 + 16);
+      })) return r;
+  gn_small_kernel<1024, true><<<dim3(B, G), 1024, (size_t)HW * cpg * sizeof(half_t) + (size_t)cpg * 8 + 16, st>>>(nullptr, x2, C1, C2, HW, G, eps, gamma, beta,
+                                                                                                          silu, out, sl);
   return (int)hipGetLastError();
 }
 

@@ -39,8 +39,12 @@ struct GemmP {
 void gemm_defaults(GemmP& p);
 // ws: fp32 scratch for split-K slabs (ws_bytes available). force_cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 64x64 split-K.
 // stats_tile_rows (out): rows per m-tile of the p.stats partials actually produced, 0 if this launch produced none
+// deferred (optional): a launch that ends in the vectorised split-K combine (alpha == 1) does NOT run it; *deferred receives the launch
+// parameters (splitk > 1; otherwise splitk = 1) and the caller either runs launch_splitk_reduce or gives the slabs to a consumer that
+// sums them itself in the same order (launch_groupnorm_slab)
 int launch_igemm(GemmP p, float* ws, size_t ws_bytes, hipStream_t st, int force_cfg = -1, int force_split = 0,
-                 int* cfg_used = nullptr, int* stats_tile_rows = nullptr);
+                 int* cfg_used = nullptr, int* stats_tile_rows = nullptr, GemmP* deferred = nullptr);
+int launch_splitk_reduce(const GemmP& p, hipStream_t st);
 int igemm_init();  // sets dynamic-LDS attributes once
 // tile configuration id / split-K of the most recent launch_igemm and the <BM, BN, BKT, NST, WGM, ABL, WK> of its igemm_dma_kernel (profiling)
 void igemm_last_launch(int* cfg, int* split, int* geom7);
@@ -61,6 +65,13 @@ int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, i
                            const float* gamma, const float* beta, int silu, half_t* out, const float* st1, int tpb1,
                            const float* st2, int tpb2, float* scratch, hipStream_t st);
 void norm_set_tuning_gn_inline_rows(int v);   // tuning "gn_inline_rows"
+// GroupNorm (one launch, small maps) whose FIRST source is still the split-K slabs of its producer GEMM: channel c < C1 of pixel m is
+// fp16(sum_z slab[z][m][c] + bias[c] + res[m][c]) -- the bits splitk_reduce_vec_kernel would have stored -- summed by the block that
+// normalises it; that fp16 tensor is also written to sum_out when non-null (a later consumer needs it: residual / skip connection).
+struct GnSlab { const float* slab; int splitk; size_t stride; const float* bias; const half_t* res; int ldres; half_t* sum_out; };
+bool groupnorm_slab_ok(int C1, int C2, int HW, int G);      // shapes the one-launch kernel takes
+int launch_groupnorm_slab(const GnSlab& sl, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
+                          const float* beta, int silu, half_t* out, hipStream_t st);
 int launch_layernorm(const half_t* x, int M, int C, float eps, const float* gamma, const float* beta, half_t* out,
                      hipStream_t st);
 int launch_geglu(const half_t* x, int M, int I, half_t* out, hipStream_t st);       // x [M][2I] -> out [M][I]

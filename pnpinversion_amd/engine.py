@@ -120,7 +120,9 @@ class NativeEngine:
                                           max_unet_rows, max_vae_images)
         if st != 0:
             msg = self.lib.pnpi_last_error(self.h if self.h else (share_weights_with.h if share_weights_with is not None else self.h))
-            raise _capi.PnpiError(st, msg.decode() if msg else "?")
+            text = msg.decode() if msg else "?"
+            self.close()                 # the half-built context only serves pnpi_last_error: free it
+            raise _capi.PnpiError(st, text)
         self.max_unet_rows = max_unet_rows
         self.max_vae_images = max_vae_images
         self.lat_hw = cfg.sample_size

@@ -394,9 +394,13 @@ class P2PEditor:
         return peers[:n]
 
     def close_peers(self):
-        """Free the extra library contexts `edit_stream_in_flight` created."""
+        """Free the extra library contexts `edit_stream_in_flight` and `edit_stream_directinversion` created (they borrow the main
+        context's weight arena: close them before the main pipeline's engine)."""
         for peer, _ in self.__dict__.pop("_peers", []):
             peer.ldm_stable.engine.close()
+        inverter = self.__dict__.pop("_inverter", None)
+        if inverter is not None:
+            inverter.engine.close()
 
     def edit_stream_in_flight(self, edit_method, items, n_flight=2, **kw):
         """ANY method string over a sequence of images with n_flight images in flight: image i runs on context i % n_flight (this

@@ -37,6 +37,7 @@ class Ctx:
                                   max_rows, max_vae)
         if st != 0:
             msg = self.lib.pnpi_last_error(self.h)
+            self.close()
             raise RuntimeError("pnpi_create failed: %d %s" % (st, msg))
 
     def call(self, name, *args):

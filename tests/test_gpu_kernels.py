@@ -46,6 +46,7 @@ def h16(*shape, scale=1.0, seed=0):
     (4096, 1536, 320, 16, 0), (384, 640, 192, 17, 0), (1000, 640, 640, 17, 0), (130, 328, 64, 17, 0), (192, 320, 2880, 17, 0), (4096, 320, 320, 17, 0),
     (512, 320, 2048, 17, 4), (768, 1280, 11520, 17, 16), (3072, 1280, 1280, 17, 0),
     (40000, 320, 128, 17, 0), (33000, 256, 64, 16, 0),          # a linear layer is one image row of M pixels: M beyond 2^15
+    (3072, 1280, 1280, 18, 0), (700, 384, 320, 18, 0), (512, 256, 4096, 18, 3), (130, 70, 72, 18, 0),   # 128x128, 128-byte rows, three stages
 ])
 def test_gemm(ctx, M, N, K, cfg, split):
     a = h16(M, K, seed=1)

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INC = os.path.join(ROOT, "pnpinversion_amd", "csrc", "tile_table.inc")
-TILE_IDS = {0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17}       # launch_igemm's configuration ids (2 is force-only; 16 / 17: the 8-wave ping-pong kernel)
+TILE_IDS = {0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16,  17, 18}       # launch_igemm's configuration ids (2 is force-only; 16 / 17: the 8-wave ping-pong kernel)
 SPLITS = {1, 2, 3, 4, 6, 8, 12, 16}                                 # the split-K factors launch_igemm's cost model also walks
 ROW = re.compile(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},")
 

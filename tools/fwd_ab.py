@@ -10,8 +10,8 @@ eng = NativeEngine(SD1, max_unet_rows=max(rows_list + [4]), max_vae_images=1)
 eng.load_state_dict({k: v.cuda() for k, v in weights.unet_state_dict(SD1, 0).items()}, {k: v.cuda() for k, v in weights.vae_state_dict(SD1, 0).items()})
 lib = eng.lib
 DEFAULTS = {"igemm_wide": 1, "gn_inline_rows": 0, "igemm_force_cfg": -1, "igemm_v320": 1, "igemm_v256n": 1, "igemm_deep_rings": 1,
-            "igemm_vt_lds": 1, "igemm_res_late": 0, "igemm_table": 1, "igemm_bias_init": 1, "igemm_sched": int(os.environ.get("FWD_AB_SCHED_DEFAULT", "0")), "tile_order": -1, "igemm_v128": 2, "attn_vt_perm": 1, "igemm_tapin": 0, "igemm_pp_only_n": 0, "attn_aug": 1}
-ARMS = {"default": {}, "no_attn_aug": {"attn_aug": 0}, "tapin": {"igemm_tapin": 1}, "no_pp": {"igemm_pp_only_n": -1}, "no_wide": {"igemm_wide": 0}, "gn_inline": {"gn_inline_rows": 1 << 20}, "no_deep_rings": {"igemm_deep_rings": 0},
+            "igemm_vt_lds": 1, "igemm_res_late": 0, "igemm_table": 1, "igemm_bias_init": 1, "igemm_sched": int(os.environ.get("FWD_AB_SCHED_DEFAULT", "0")), "tile_order": -1, "igemm_v128": 2, "attn_vt_perm": 1, "igemm_tapin": 0, "igemm_pp_only_n": 0, "attn_aug": 1, "gn_slab": 0}
+ARMS = {"default": {}, "gn_slab": {"gn_slab": 1}, "no_attn_aug": {"attn_aug": 0}, "tapin": {"igemm_tapin": 1}, "no_pp": {"igemm_pp_only_n": -1}, "no_wide": {"igemm_wide": 0}, "gn_inline": {"gn_inline_rows": 1 << 20}, "no_deep_rings": {"igemm_deep_rings": 0},
         "no_vt_lds": {"igemm_vt_lds": 0}, "res_late": {"igemm_res_late": 1}, "no_table": {"igemm_table": 0}, "no_bias_init": {"igemm_bias_init": 0},
         "order0": {"tile_order": 0}, "order1": {"tile_order": 1}, "order2": {"tile_order": 2},
         "f0_v2": {"igemm_force_cfg": 0, "igemm_v128": 2, "attn_vt_perm": 1, "igemm_tapin": 0, "igemm_pp_only_n": 0, "attn_aug": 1}, "f0_v3": {"igemm_force_cfg": 0, "igemm_v128": 3}, "f0_v8": {"igemm_force_cfg": 0, "igemm_v128": 8},

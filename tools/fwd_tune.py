@@ -13,9 +13,9 @@ from pnpinversion_amd import weights
 from pnpinversion_amd.config import SD1
 from pnpinversion_amd.engine import NativeEngine
 rows_list = [int(a) for a in sys.argv[1:]] or [12, 1]
-NAME = {0: "128", 1: "64", 3: "256m", 4: "320", 5: "256n", 6: "256x320", 7: "256x256", 8: "64k4", 9: "128k2", 10: "128k2b", 11: "64k2", 12: "64x320", 13: "128n2", 14: "128b64", 15: "256nb64", 16: "pp256", 17: "pp320"}
-SINGLE = [0, 1, 3, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8, 16, 17]
-SPLIT_CFGS = [0, 1, 4, 5, 11, 14, 16, 17]
+NAME = {0: "128", 1: "64", 3: "256m", 4: "320", 5: "256n", 6: "256x320", 7: "256x256", 8: "64k4", 9: "128k2", 10: "128k2b", 11: "64k2", 12: "64x320", 13: "128n2", 14: "128b64", 15: "256nb64", 16: "pp256", 17: "pp320", 18: "128b64x3"}
+SINGLE = [0, 1, 3, 4, 5, 12, 13, 14, 15, 10, 11, 9, 8, 16, 17, 18]
+SPLIT_CFGS = [0, 1, 4, 5, 11, 14, 16, 17, 18]
 SPLITS = [2, 3, 4, 6, 8, 12, 16]
 VAE = os.environ.get("FWD_TUNE_WORK") == "vae"
 if VAE and not sys.argv[1:]: rows_list = [1, 2]
@@ -42,6 +42,7 @@ for rows in rows_list:
     combos = [(-1, 0)] + [(c, 0) for c in SINGLE] + [(c, s) for s in SPLITS for c in SPLIT_CFGS]
     if os.environ.get("FWD_TUNE_CFGS"):        # quick look at a few configurations: FWD_TUNE_CFGS="3,14"
         combos = [(-1, 0)] + [(int(c), 0) for c in os.environ["FWD_TUNE_CFGS"].split(",")]
+        combos += [(int(c), int(s)) for c in os.environ["FWD_TUNE_CFGS"].split(",") for s in os.environ.get("FWD_TUNE_SPLITS", "").split(",") if s]
     us = collections.defaultdict(lambda: collections.defaultdict(float))    # shape -> "name/sN" -> us per forward (sum of its launches)
     cnt = collections.defaultdict(int)
     total = {}
