@@ -18,6 +18,8 @@ ARMS = {"default": {}, "gn_slab": {"gn_slab": 1}, "no_attn_aug": {"attn_aug": 0}
         "f0_v1": {"igemm_force_cfg": 0, "igemm_v128": 1}, "f0_v0": {"igemm_force_cfg": 0, "igemm_v128": 0}, "f14": {"igemm_force_cfg": 14},
         "no_vt_perm": {"attn_vt_perm": 0},
         "sched": {"igemm_sched": 1}, "sched2": {"igemm_sched": 2}, "sched0": {"igemm_sched": 0}}
+for kv in filter(None, os.environ.get("FWD_AB_DEFAULTS", "").split(",")):      # FWD_AB_DEFAULTS="gn_slab=1": what the default arm and the dump run with
+    DEFAULTS[kv.split("=")[0]] = int(kv.split("=")[1])
 if os.environ.get("FWD_AB_ARMS"): ARMS = {k: v for k, v in ARMS.items() if k in os.environ["FWD_AB_ARMS"].split(",")}
 def setk(d):
     for k, v in {**DEFAULTS, **d}.items(): assert lib.pnpi_set_tuning(k.encode(), v) == 0, k
