@@ -223,6 +223,25 @@ def test_pingpong_conv_random_shapes(ctx, B, C1, C2, H, N, stride, pad, ups, cfg
     test_conv3x3(ctx, B, C1, C2, H, N, stride, pad, ups, cfg, split)
 
 
+@pytest.mark.parametrize("cfg", [16, 17])
+@pytest.mark.parametrize("stride,pad,ups,H", [(1, 1, 0, 9), (2, 1, 0, 15), (2, 0, 0, 16), (1, 1, 1, 7)])
+def test_pingpong_conv_out_of_range_lanes_write_zeros_into_poisoned_lds(ctx, cfg, stride, pad, ups, H):
+    """conv padding, rows past M and tail K-tiles of the ping-pong kernel rely on `buffer_load ... lds` writing ZEROS for lanes
+    whose offset is >= num_records.  If such a lane skipped its LDS write, whatever the previous launch left in LDS would be multiplied
+    in: so a GEMM with +-30 000 operands runs first on the same stream (every CU's LDS full of them), then a convolution with a padded
+    border, M % BM != 0 (B H W = 3 x odd^2), stride 2 / asymmetric pad / folded upsample -- border rows, tail rows and the whole output
+    against F.conv2d.  Stale values of that size would turn the result into garbage, not into a rounding difference."""
+    big = torch.full((1024, 512), 30000.0, dtype=torch.half, device=DEV)
+    big[::2] = -30000.0
+    wbig = torch.full((512, 512), 1.0, dtype=torch.half, device=DEV)
+    sink = torch.empty(1024, 512, dtype=torch.half, device=DEV)
+    ctx.call("pnpi_op_gemm", ptr(big), 512, ptr(wbig), 512, 1024, 512, 512, 1e-6, None, None, ptr(sink), 512, 1 << 30, None, 0, 0, 1, cfg, 0)
+    test_conv3x3(ctx, 3, 128, 64, H, 328, stride, pad, ups, cfg, 0)
+    # and with split-K: the last K slice of a tile is a partial walk
+    ctx.call("pnpi_op_gemm", ptr(big), 512, ptr(wbig), 512, 1024, 512, 512, 1e-6, None, None, ptr(sink), 512, 1 << 30, None, 0, 0, 1, cfg, 0)
+    test_conv3x3(ctx, 3, 128, 64, H, 328, stride, pad, ups, cfg, 3)
+
+
 # ------------------------------------------------------------------------------------------------ conv
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
