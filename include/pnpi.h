@@ -118,6 +118,11 @@ typedef struct {
   float recon_lr;
   int recon_t;
   int dilate_mask;                 /* radius of the max-pool dilation of mask_edit; 0 = none */
+  /* inversion guidance (proximal_guidance_forward.py:73-75): inv_x_stars = the inversion trajectory x*_0 .. x*_nsteps, device fp32
+   * [nsteps+1][nimg][4][h][w] (nullable = off); at step i inside the recon_t window the step's result is pulled towards
+   * x*_{nsteps-1-i} outside the edit mask with recon_lr.  ref_image may then be NULL (no pred-x0 pull).  pnpi_cfg_ddim_prev (level 1,
+   * one step, no step index): inv_x_stars points at THIS step's x*_{t-1}, [nimg][4][h][w]. */
+  const float* inv_x_stars;
 } pnpi_recon_desc;
 
 typedef struct {

@@ -484,6 +484,55 @@ def proximal_recon(steps=4):
     np.savez_compressed(os.path.join(OUT, "e2e_proximal_recon.npz"), **out)
 
 
+def proximal_inv_guidance(steps=4):
+    """Inversion guidance of proximal_guidance_forward (models/p2p/proximal_guidance_forward.py:73-75), which no reference editor switches on
+    (p2p_editor.py:368,593 pass inversion_guidance=False): the reference's own function, reached through its own editor
+    ("negative-prompt-inversion+proximal-guidance", use_inversion_guidance=True -> recon_lr / recon_t / x_stars are passed on) with
+      pos: inversion_guidance=True injected into the edit-stage call, recon_t = 400 (pull active at t = 250, 0 of the 4 steps), recon_lr 0.5
+      neg: NO injection, recon_t = -600 in the edit-stage call: by the operator precedence of :73 the pull runs at t > 600 (t = 750) whatever
+           the flag says (the editor itself cannot pass a negative recon_t: its reconstruction pass then dies on `1 - None`, :78)
+      off: the same call without either (the effect under test must be resolved against it)."""
+    ref_shim.install()
+    cfg = SMALL64
+    usd, vsd = weights.unet_state_dict(cfg, 2), weights.vae_state_dict(cfg, 2)
+    ed = ref_shim.build_editor(cfg, usd, vsd, WordTokenizer(), SyntheticTextEncoder(cfg.cross_dim, seed=7), steps)
+    src, tgt, w0, w1 = PROMPT_PAIRS[0]
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")))[:, :, :3]
+    import models.p2p_editor as pe
+    out = {"steps": np.int64(steps), "src": src, "tgt": tgt, "blend": np.array([w0, w1]), "recon_lr": np.float32(0.5), "dilate_mask": np.int64(1)}
+    for name, recon_t, inject in (("pos", 400, True), ("neg", -600, False), ("off", 400, False)):
+        calls = []
+        saved = pe.proximal_guidance_forward
+
+        def spy(*a, **k):
+            if k.get("edit_stage") and k.get("prox") is not None:
+                if inject:
+                    k["inversion_guidance"] = True
+                k["recon_t"] = recon_t          # (a negative recon_t crashes the editor's reconstruction pass -- `1 - None`, :78: edit stage only)
+            r = saved(*a, **k)
+            calls.append(r[0].clone().numpy())
+            return r
+
+        pe.proximal_guidance_forward = spy
+        try:
+            with ref_shim.cuda_to_cpu(), torch.no_grad():
+                panel = ed("negative-prompt-inversion+proximal-guidance", image_path=img, prompt_src=src, prompt_tar=tgt,
+                           guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+                           eq_params={"words": (w1,), "values": (2,)}, proximal="l0", quantile=0.75, use_inversion_guidance=True,
+                           recon_lr=0.5, recon_t=400, dilate_mask=1)
+        finally:
+            pe.proximal_guidance_forward = saved
+        assert len(calls) == 2
+        out[name + "/recon_t"] = np.int64(recon_t)
+        out[name + "/reconstruct_latent"], out[name + "/edited_latents"] = calls
+        out[name + "/edited_image_small"] = np.array(panel)[::4, 3 * 512::4]
+        print("proximal_inv_guidance", name, float(np.abs(calls[1]).mean()))
+    d = lambda a, b: float(np.linalg.norm(out[a + "/edited_latents"] - out[b + "/edited_latents"]) / np.linalg.norm(out[b + "/edited_latents"]))
+    print("pull on vs off: pos %.3e, neg %.3e" % (d("pos", "off"), d("neg", "off")))
+    np.savez_compressed(os.path.join(OUT, "proximal_inv_guidance.npz"), **out)
+
+
 def null_text(steps=3, cfg=SMALL64, seed=2, name="e2e_null_text"):
     """cfg=SD1 (name e2e_null_text_sd1, 2 steps x 10 Adam iterations, weight seed 0): BASELINE config 4 at the benchmarked width.
     P2PEditor("null-text-inversion+p2p") of the reference (models/p2p_editor.py:199-259): NullInversion.invert = ddim_inversion +
@@ -756,6 +805,8 @@ if __name__ == "__main__":
         proximal()
     if "proximal_recon" in which or not sys.argv[1:]:
         proximal_recon()
+    if "proximal_inv_guidance" in which or not sys.argv[1:]:
+        proximal_inv_guidance()
     if "null_text" in which or not sys.argv[1:]:
         null_text()
     if "unet_ctxgrad_sd1" in which:

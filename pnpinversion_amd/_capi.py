@@ -40,7 +40,7 @@ class CtrlDesc(C.Structure):
 
 
 class ReconDesc(C.Structure):
-    _fields_ = [("ref_image", C.c_void_p), ("recon_lr", C.c_float), ("recon_t", C.c_int), ("dilate_mask", C.c_int)]
+    _fields_ = [("ref_image", C.c_void_p), ("recon_lr", C.c_float), ("recon_t", C.c_int), ("dilate_mask", C.c_int), ("inv_x_stars", C.c_void_p)]
 
 
 ATTN_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)

@@ -532,8 +532,8 @@ int pnpi_ddim_prev_step_recon(pnpi_ctx* c, const float* eps, int t, int ratio, c
   CK(launch_ddim_prev_recon(sample, eps, af, at, on ? ref_image : nullptr, recon_lr, on ? recon_mask : nullptr, n, out, pred_x0_out, c->st));
   return 0;
 }
-static bool recon_active(const pnpi_recon_desc* rc, int t) {   // proximal_guidance_forward.py:48,60
-  return rc && rc->ref_image && rc->recon_lr > 0.f && ((rc->recon_t > 0 && t < rc->recon_t) || (rc->recon_t < 0 && t > -rc->recon_t));
+static bool recon_active(const pnpi_recon_desc* rc, int t) {   // proximal_guidance_forward.py:48,60 (and :73 for the inversion pull)
+  return rc && (rc->ref_image || rc->inv_x_stars) && rc->recon_lr > 0.f && ((rc->recon_t > 0 && t < rc->recon_t) || (rc->recon_t < 0 && t > -rc->recon_t));
 }
 
 int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, int rpi, size_t row_elems, float gs, int t, int ratio,
@@ -544,7 +544,8 @@ int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, 
   const bool rc = prox && recon_active(recon, t);
   const int S = c->cfg.sample_size;
   CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_scale, offset_out, x_out, c->st,
-                          prox_threshold, prox, rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, S, S));
+                          prox_threshold, prox, rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, S, S,
+                          rc ? recon->inv_x_stars : nullptr));        // level 1: the caller points inv_x_stars at this step's x*_{t-1} [nimg][...]
   return 0;
 }
 
@@ -780,9 +781,11 @@ static int edit_loop_impl(pnpi_ctx* c, const float* x_T, int nimg, const float* 
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
     if (prox && quantile > 0.f) CK(launch_quantile_abs_diff(eps, nimg, 2, E, quantile, thr, c->st));
     const bool rc = prox && recon_active(recon, t);
+    // inversion guidance: x_stars[len(x_stars) - i - 2] (proximal_guidance_forward.py:75), one latent per image for both of its rows
+    const float* inv = (rc && recon->inv_x_stars) ? recon->inv_x_stars + (size_t)(nsteps - 1 - i) * nimg * E : nullptr;
     CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st, prox ? thr : nullptr, prox,
                             rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, g.sample_size,
-                            g.sample_size));
+                            g.sample_size, inv));
     if (use_ctrl) CKP(apply_local_blend(c, lat, i));
   }
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));

@@ -174,7 +174,8 @@ int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_pe
                          float a_t, float a_prev, const float* noise_loss, int offset_rows, const float* target,
                          float offset_scale, float* offset_out, float* x_out, hipStream_t st, const float* prox_thr = nullptr,
                          int prox_mode = 0, const float* recon_ref = nullptr, float recon_lr = 0.f, int dilate = 0, int lat_h = 0,
-                         int lat_w = 0);   // recon_ref [nimg][row_elems]: reconstruction guidance (needs prox_mode)
+                         int lat_w = 0, const float* inv_ref = nullptr);   // recon_ref [nimg][row_elems]: reconstruction guidance; inv_ref
+                                                                          // [nimg][row_elems]: inversion guidance (both need prox_mode)
 // threshold of the proximal-guidance step: quantile q of |eps_c - eps_u| over the rows of each image (torch.quantile, linear)
 int launch_quantile_abs_diff(const float* eps, int nimg, int rows_per_img, size_t row_elems, float q, float* thr_out, hipStream_t st);
 int launch_fill_f32(float* p, int n, float v, hipStream_t st);

@@ -84,11 +84,14 @@ __device__ __forceinline__ float prox_shrink(float d, float th, int mode) {
 // recon_ref != null (reconstruction guidance, proximal_guidance_forward.py:48-51,60-72 + DDIMSchedulerDev.step scheduler_dev.py:68-76):
 //   mask_edit = |shrunk delta| > thr, dilated by a (2*dil+1)^2 max-pool over each [h][w] plane (in-bounds neighbours only);
 //   pred_x0 -= recon_lr * (pred_x0 - ref[img]) * (1 - mask_edit)   before the step's second half
+// inv_ref != null (inversion guidance, proximal_guidance_forward.py:73-75): the step's RESULT is pulled towards the inversion trajectory
+//   outside the same mask: x_out -= recon_lr * (x_out - inv_ref[img]) * (1 - mask_edit), inv_ref = x*_{t-1} for both rows of the image
 __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float* __restrict__ x, int nimg, int R, size_t E, float g,
                                      float sa_f, float sb_f, float sa_t, float sb_t, const float* __restrict__ noise_loss,
                                      int offset_rows, const float* __restrict__ target, float oscale,
                                      float* __restrict__ offset_out, float* __restrict__ x_out, const float* __restrict__ prox_thr,
-                                     int prox_mode, const float* __restrict__ recon_ref, float recon_lr, int dil, int lat_h, int lat_w) {
+                                     int prox_mode, const float* __restrict__ recon_ref, float recon_lr, int dil, int lat_h, int lat_w,
+                                     const float* __restrict__ inv_ref) {
   const size_t total = (size_t)nimg * R * E;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t e_idx = i % E;
@@ -104,7 +107,7 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
     if (prox_mode) d = prox_shrink(d, th, prox_mode);
     float e = __fadd_rn(eu, __fmul_rn(g, d));
     float prev;
-    if (recon_ref && prox_mode) {
+    if ((recon_ref || inv_ref) && prox_mode) {
       float mask_edit = fabsf(d) > th ? 1.f : 0.f;
       if (dil > 0 && mask_edit == 0.f) {
         const int hw = lat_h * lat_w;
@@ -119,9 +122,14 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
           }
       }
       const float recon_mask = __fsub_rn(1.f, mask_edit);
-      float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(sb_f, e)), sa_f);
-      x0 = __fsub_rn(x0, __fmul_rn(__fmul_rn(recon_lr, __fsub_rn(x0, recon_ref[(size_t)img * E + e_idx])), recon_mask));
-      prev = __fadd_rn(__fmul_rn(sa_t, x0), __fmul_rn(sb_t, e));
+      if (recon_ref) {
+        float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(sb_f, e)), sa_f);
+        x0 = __fsub_rn(x0, __fmul_rn(__fmul_rn(recon_lr, __fsub_rn(x0, recon_ref[(size_t)img * E + e_idx])), recon_mask));
+        prev = __fadd_rn(__fmul_rn(sa_t, x0), __fmul_rn(sb_t, e));
+      } else {
+        prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
+      }
+      if (inv_ref) prev = __fsub_rn(prev, __fmul_rn(__fmul_rn(recon_lr, __fsub_rn(prev, inv_ref[(size_t)img * E + e_idx])), recon_mask));
     } else {
       prev = ddim_update(x[i], e, sa_f, sb_f, sa_t, sb_t);
     }
@@ -142,16 +150,16 @@ __global__ void cfg_ddim_prev_kernel(const float* __restrict__ eps, const float*
 int launch_cfg_ddim_prev(const float* eps, const float* x, int nimg, int rows_per_img, size_t row_elems, float gscale, float a_t,
                          float a_prev, const float* noise_loss, int offset_rows, const float* target, float offset_scale,
                          float* offset_out, float* x_out, hipStream_t st, const float* prox_thr, int prox_mode, const float* recon_ref,
-                         float recon_lr, int dilate, int lat_h, int lat_w) {
+                         float recon_lr, int dilate, int lat_h, int lat_w, const float* inv_ref) {
   float sa_f = sqrtf(a_t), sb_f = sqrtf(1.0f - a_t), sa_t = sqrtf(a_prev), sb_t = sqrtf(1.0f - a_prev);
   size_t total = (size_t)nimg * rows_per_img * row_elems;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  if (recon_ref && (lat_h <= 0 || lat_w <= 0 || row_elems % ((size_t)lat_h * lat_w))) return -3;
+  if ((recon_ref || inv_ref) && (lat_h <= 0 || lat_w <= 0 || row_elems % ((size_t)lat_h * lat_w))) return -3;
   cfg_ddim_prev_kernel<<<blocks, 256, 0, st>>>(eps, x, nimg, rows_per_img, row_elems, gscale, sa_f, sb_f, sa_t, sb_t, noise_loss,
                                                offset_rows, target, offset_scale, offset_out, x_out, prox_thr, prox_mode, recon_ref,
-                                               recon_lr, dilate, lat_h, lat_w);
+                                               recon_lr, dilate, lat_h, lat_w, inv_ref);
   return (int)hipGetLastError();
 }
 

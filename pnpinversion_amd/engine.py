@@ -395,6 +395,23 @@ class NativeEngine:
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int32))
         return ts, ts.ctypes.data_as(C.POINTER(C.c_int))
 
+    def _recon_desc(self, recon, nimg, xT, nsteps):
+        """recon dict -> (pnpi_recon_desc, tensors to keep alive).  ref_image: [nimg,4,h,w] encoded source latent or None; x_stars: None
+        or the inversion trajectory [nsteps+1, 1 | nimg, 4, h, w] (inversion guidance, proximal_guidance_forward.py:73-75)."""
+        if recon is None:
+            return None, None
+        ref = inv = None
+        if recon.get("ref_image") is not None:
+            ref = self._f32(recon["ref_image"]).reshape(nimg, *xT.shape[1:]).contiguous()
+        if recon.get("x_stars") is not None:
+            xs = recon["x_stars"]
+            xs = torch.stack([x for x in xs]) if isinstance(xs, (list, tuple)) else xs
+            inv = self._f32(xs).reshape(nsteps + 1, -1, *xT.shape[1:])
+            inv = inv.expand(nsteps + 1, nimg, *xT.shape[1:]).contiguous()
+        rd = _capi.ReconDesc(ref.data_ptr() if ref is not None else None, float(recon["recon_lr"]), int(recon["recon_t"]),
+                             int(recon.get("dilate_mask") or 0), inv.data_ptr() if inv is not None else None)
+        return rd, (ref, inv)
+
     def edit_loop_uncond_steps(self, x_T, context4, uncond_steps, ctrls, timesteps, guidance_scale, first_only=False, prox=None, quantile=0.7,
                                recon=None):
         """edit_loop with per-step unconditional embeddings [steps, nimg, 77, D] (null-text inversion); recon as in edit_loop."""
@@ -404,10 +421,7 @@ class NativeEngine:
         ts, tsp = self._ts(timesteps)
         arr = _desc_array(ctrls)
         mode = {None: 0, "l0": 1, "l1": 2}[prox]
-        rd, ref = None, None
-        if recon is not None:
-            ref = self._f32(recon["ref_image"]).reshape(nimg, *xT.shape[1:]).contiguous()
-            rd = _capi.ReconDesc(ref.data_ptr(), float(recon["recon_lr"]), int(recon["recon_t"]), int(recon.get("dilate_mask") or 0))
+        rd, ref = self._recon_desc(recon, nimg, xT, len(timesteps))
         self._call("pnpi_edit_loop_uncond_steps_recon", _p(xT), nimg, _p(ctx), arr, len(timesteps), tsp, float(guidance_scale), mode, float(quantile),
                    _p(us), int(bool(first_only)), C.byref(rd) if rd is not None else None, _p(out))
         self._keep = (xT, ctx, us, ts, arr, ctrls, ref, rd)
@@ -539,10 +553,7 @@ class NativeEngine:
         ts, tsp = self._ts(timesteps)
         arr = _desc_array(ctrls)
         mode = {None: 0, "l0": 1, "l1": 2}[prox]
-        rd, ref = None, None
-        if recon is not None:
-            ref = self._f32(recon["ref_image"]).reshape(nimg, *xT.shape[1:]).contiguous()
-            rd = _capi.ReconDesc(ref.data_ptr(), float(recon["recon_lr"]), int(recon["recon_t"]), int(recon.get("dilate_mask") or 0))
+        rd, ref = self._recon_desc(recon, nimg, xT, n)
         self._call("pnpi_edit_loop", _p(xT), nimg, _p(ctx), _p(nl), int(offset_rows), arr, n, tsp, float(guidance_scale), mode,
                    float(quantile), C.byref(rd) if rd is not None else None, _p(out))
         self._keep = (xT, ctx, nl, ts, arr, ctrls, ref, rd)

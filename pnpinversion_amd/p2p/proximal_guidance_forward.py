@@ -7,8 +7,12 @@ quantile=0.75, use_inversion_guidance=True, recon_lr=1, recon_t=400):
   * reconstruction guidance (image_enc given, :48-51,60-72 + DDIMSchedulerDev.step's ref_image branch, scheduler_dev.py:68-76; the
     editors pass it with use_reconstruction_guidance=True): at t inside the recon_t window the predicted x0 is pulled towards the
     encoded source image outside the dilated edit mask -- same kernel (pnpi_recon_desc);
-  * inversion guidance (:73-75): the editors never pass inversion_guidance=True to this function, and with the default False the
-    condition `mask_edit is not None and inversion_guidance and (...) or (recon_t < 0 and ...)` is False for recon_t > 0 -- inert."""
+  * inversion guidance (:73-75): `mask_edit is not None and inversion_guidance and (recon_t > 0 and t < recon_t) or (recon_t < 0 and
+    t > -recon_t)` -- by operator precedence the pull of the step's result towards x_stars[len(x_stars) - i - 2] outside the edit mask
+    runs (a) with inversion_guidance=True inside a positive recon_t window, and (b) ALWAYS inside a negative recon_t window (t > -recon_t),
+    flag or not -- where the reference then needs x_stars and a mask (it raises TypeError on `1 - None` otherwise; here: ValueError).
+    Same kernel (pnpi_recon_desc::inv_x_stars).  No reference editor passes inversion_guidance=True or a negative recon_t
+    (p2p_editor.py:368,593 hard-code False); tests/golden/proximal_inv_guidance.npz is a direct call of the reference's function."""
 import torch
 
 from .p2p_guidance_forward import p2p_guidance_forward
@@ -20,11 +24,13 @@ def proximal_guidance_forward(model, prompt, controller, guidance_scale=7.5, gen
                               inversion_guidance=False, x_stars=None, dilate_mask=None, num_inference_steps=None):
     if edit_stage and prox is not None and prox not in ("l0", "l1"):
         raise NotImplementedError
-    if inversion_guidance or recon_t < 0:
-        raise NotImplementedError("inversion guidance / negative recon_t are not built (no reference editor passes them)")
     recon = None
-    if edit_stage and prox is not None and image_enc is not None and recon_lr > 0:
-        recon = dict(ref_image=image_enc, recon_lr=recon_lr, recon_t=recon_t, dilate_mask=dilate_mask or 0)
+    if edit_stage and prox is not None:
+        pull = (inversion_guidance and recon_t > 0) or recon_t < 0          # the reference's precedence (see above)
+        if pull and x_stars is None:
+            raise ValueError("inversion guidance (inversion_guidance=True, or any negative recon_t) needs x_stars")
+        if recon_lr > 0 and (image_enc is not None or pull):
+            recon = dict(ref_image=image_enc, recon_lr=recon_lr, recon_t=recon_t, dilate_mask=dilate_mask or 0, x_stars=x_stars if pull else None)
     steps = num_inference_steps if num_inference_steps is not None else model.scheduler.num_inference_steps
     return p2p_guidance_forward(model=model, prompt=prompt, controller=controller, num_inference_steps=steps,
                                 guidance_scale=guidance_scale, generator=generator, latent=latent, uncond_embeddings=uncond_embeddings,

@@ -254,7 +254,8 @@ class P2PEditor:
             if proximal is not None and len(k["prompt"]) == 2:
                 return proximal_guidance_forward(num_inference_steps=self.num_ddim_steps, edit_stage=True, prox=proximal, quantile=quantile,
                                                  image_enc=image_enc_latent if use_reconstruction_guidance else None,
-                                                 recon_lr=recon_lr if on else 0, recon_t=recon_t if on else 1000, dilate_mask=dilate_mask, **k)
+                                                 recon_lr=recon_lr if on else 0, recon_t=recon_t if on else 1000, dilate_mask=dilate_mask,
+                                                 inversion_guidance=False, x_stars=x_stars, **k)     # as p2p_editor.py:593,632
             return base(num_inference_steps=self.num_ddim_steps, **k)
         out = self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                               self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)
@@ -297,6 +298,7 @@ class P2PEditor:
             return proximal_guidance_forward(edit_stage=edit, prox=proximal if edit else None, quantile=quantile,
                                              image_enc=image_enc_latent if (edit and use_reconstruction_guidance) else None,
                                              recon_lr=recon_lr if on else 0, recon_t=recon_t if on else 1000, dilate_mask=dilate_mask,
+                                             inversion_guidance=False, x_stars=x_stars if edit else None,       # as p2p_editor.py:368-369,407
                                              num_inference_steps=self.num_ddim_steps, **k)
         return self._plain_p2p(fwd, image_gt, x_stars, uncond_embeddings, prompt_src, prompt_tar, guidance_scale, cross_replace_steps,
                                self_replace_steps, blend_word, eq_params, is_replace_controller, side, return_stages)

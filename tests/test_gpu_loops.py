@@ -660,6 +660,54 @@ def test_reconstruction_guidance_against_reference_golden(small64, prox):
     small64.scheduler.set_timesteps(2)
 
 
+@pytest.mark.parametrize("name", ["pos", "neg"])
+def test_inversion_guidance_against_reference_golden(small64, name, monkeypatch):
+    """proximal_guidance_forward's inversion guidance (models/p2p/proximal_guidance_forward.py:73-75: the step's result pulled towards the
+    inversion trajectory outside the dilated edit mask) -- no reference editor switches it on, so the fixture is the reference's own function
+    under its own editor with the flag injected into the edit-stage call (tests/golden/proximal_inv_guidance.npz, oracle/make_golden.py
+    proximal_inv_guidance): `pos` = inversion_guidance=True, recon_t 400 (pull at t = 250, 0); `neg` = recon_t -600 and NO flag: by the
+    operator precedence of :73 the pull still runs (t = 750).  The same injection here, into the product's function."""
+    import pnpinversion_amd.p2p_editor as pe
+    v = np.load(os.path.join(GOLD, "proximal_inv_guidance.npz"))
+    steps = int(v["steps"])
+    ed = P2PEditor(["negative-prompt-inversion+proximal-guidance"], "cuda", num_ddim_steps=steps, pipeline=small64)
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "example_cat_512.png")))[:, :, :3]
+    w0, w1 = [str(x) for x in v["blend"]]
+    kw = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6, blend_word=((w0,), (w1,)),
+              eq_params={"words": (w1,), "values": (2,)}, proximal="l0", quantile=0.75, recon_lr=float(v["recon_lr"]), recon_t=400,
+              dilate_mask=int(v["dilate_mask"]), use_inversion_guidance=True)
+    real = pe.proximal_guidance_forward
+
+    def run(which):
+        def spy(**k):
+            if k.get("edit_stage") and k.get("prox") is not None and which != "off":
+                if which == "pos":
+                    k["inversion_guidance"] = True
+                k["recon_t"] = int(v[which + "/recon_t"])
+            return real(**k)
+        monkeypatch.setattr(pe, "proximal_guidance_forward", spy)
+        _, st = ed.edit_image_negative_prompt_inversion(img, str(v["src"]), str(v["tgt"]), return_stages=True, **kw)
+        monkeypatch.setattr(pe, "proximal_guidance_forward", real)
+        return st["latents"]
+
+    got, off = run(name), run("off")
+    ref, ref_off = torch.from_numpy(v[name + "/edited_latents"]), torch.from_numpy(v["off/edited_latents"])
+    # as in the reconstruction-guidance test: the edit mask is a hard threshold on a quantile; elements within fp16 noise of it fall on the
+    # other side than in the fp32 reference and switch a pull of recon_lr = 0.5 on or off
+    # (`pos` applies it at two steps, each on the latents the previous pull already moved: measured 11 % of the latent pixels beyond 0.25,
+    # 2.4e-2 outside them; `neg` at one step)
+    max_frac = 0.16 if name == "pos" else 0.08
+    r_all = rel(got, ref)
+    r, frac = masked_rel(got, ref, tol_frac=max_frac)
+    effect = rel(ref_off, ref)
+    print("inversion guidance %s: latent rel %.3e (outside %.2f%% flipped pixels %.3e); pull on vs off in the reference %.3e, here %.3e"
+          % (name, r_all, 100 * frac, r, effect, rel(off, got)))
+    assert rel(off, ref_off) < 2.5e-2                                   # the run without the pull is the plain proximal edit
+    assert frac <= max_frac and r < 4e-2 and r_all < 0.2 * effect, (name, r, frac, r_all, effect)
+    small64.scheduler.set_timesteps(2)
+
+
 def test_masactrl_driver_cli(tmp_path, capsys):
     """run_editing_masactrl.py end to end (both methods, native CLIP text encoder) on a 2-image PIE-Bench-shaped directory."""
     import json
