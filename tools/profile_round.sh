@@ -14,6 +14,11 @@ tail -c 600 "$OUT/bench_under_trace.json"
 find "$OUT/kt" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 python -c "import json; from pnpinversion_amd.build import source_hash; json.dump({'source_sha16': source_hash(), 'command': 'rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline'}, open('$OUT/kernel_stats.meta.json', 'w'))"
 head -12 "$OUT/kernel_stats.csv"
+# BASELINE config 3's launch shape (8 images per set of launches: 8-row inversion, 96-row lock-step forwards) under the same tracer
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/kt96" -o kt96 --output-format csv -- python tools/batched_only.py 8 50 1 > "$OUT/batched_under_trace.json" 2> "$OUT/kt96.err"
+tail -c 300 "$OUT/batched_under_trace.json"
+find "$OUT/kt96" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/batched8_kernel_stats.csv"
+find "$OUT/kt96" -name "*kernel_trace.csv" -delete
 # The counter passes run the SAME command with two DDIM steps instead of fifty: rocprofv3's counter service segfaults inside its dispatch
 # interception once a process has launched some tens of thousands of kernels (a full edit is ~50 000 launches, plus the event-bracketed
 # profiling edit; tools/fwd_only.py with 1 600 never tripped it).  Same kernels, same launch shapes, same 1 : 1 mix of one-row and
