@@ -290,7 +290,12 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
                        const void* residual_f16, int N, void* out_nhwc_f16, int force_cfg, int force_split, float* stats_out,
                        int* tile_rows_out);
 /* process-wide kernel tuning knobs: variant A/B inside one process (tools/fwd_ab.py, tools/fwd_tune.py) and tests of non-default
- * variants; PNPI_EINVAL for an unknown key.  Keys (default): "text_kv" (1) / "temb_cache" (1) per-loop caches; "gn_inline_rows" (0)
+ * variants; PNPI_EINVAL for an unknown key.  They are plain process globals read by every context's launches: set them while no other
+ * thread is inside a pnpi_* call (the product never calls this; several contexts on several threads -- P2PEditor.edit_stream_in_flight --
+ * only READ them).  "igemm_vpp" / "igemm_sched" / "igemm_v128" = 11, 12, 15 need a library built with `build.py --ablations`
+ * (-DPNPI_ABLATIONS=1); the product library answers them with an argument error at the launch.  "gn_slab" (0): 1 = a split-K launch whose
+ * output goes to a small-map GroupNorm leaves its combine to that kernel (bit-identical, measured slower: profiles/round5_gn_slab_ab.txt).
+ * Keys (default): "text_kv" (1) / "temb_cache" (1) per-loop caches; "gn_inline_rows" (0)
  * one-launch GroupNorm below this many rows; "igemm_dma" (1) LDS-DMA kernel family; "igemm_table" (1) measured tile table before the
  * cost model; "igemm_wide" (1) 128x320 / 128x256 tiles; "igemm_deep_rings" (1) deeper LDS rings on sparse launches; "igemm_vt_lds" (1)
  * transposed V^T epilogue through LDS; "igemm_bias_init" (1) bias as the accumulators' initial value; "igemm_sched" (0 / 1) hand-scheduled GEMM main loop (fragment
