@@ -329,7 +329,8 @@ static int launch_pp(const GemmP& p_in, dim3 grid, hipStream_t st, const half_t*
   constexpr int lds = GEO::LDS;
   static DeviceOnce attr_once;
   if (int r = once_per_device(attr_once, [&]() { return (int)hipFuncSetAttribute((const void*)igemm_pp_kernel<BM, BN, MI0, NI0, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); })) return r;
-  igemm_pp_kernel<BM, BN, MI0, NI0, ABL><<<grid, GEO::NT, lds, st>>>(p, zero_page);
+  (void)zero_page;      // the ping-pong kernel's out-of-range lanes read zeros through the buffer descriptor's bounds check (igemm_pp.inc)
+  igemm_pp_kernel<BM, BN, MI0, NI0, ABL><<<grid, GEO::NT, lds, st>>>(p);
   return 0;
 }
 

@@ -291,9 +291,13 @@ static int gn_small_max() {     // elements per (sample, group) slice handled by
   static const int v = getenv("PNPI_GN_SMALL_MAX") ? std::min(atoi(getenv("PNPI_GN_SMALL_MAX")), GN_SMALL_ELEMS) : GN_SMALL_ELEMS;
   return v;
 }
-static bool gn_small_ok(int C1, int C2, int HW, int G) {
+// B (optional): at 48 rows and more (1536 blocks) only slices up to 8 192 elements take the one-launch kernel -- with six blocks per CU
+// the streaming statistics / finalize / apply passes are faster on the larger slices (96-row forward 94.2 -> 93.4 ms, no difference at 12 rows;
+// round 5, PNPI_GN_SMALL_MAX sweep)
+static bool gn_small_ok(int C1, int C2, int HW, int G, int B = 0) {
   const int C = C1 + C2, cpg = C / G;
-  return (cpg % 4 == 0) && (C1 % 4 == 0) && cpg <= 1024 && ((size_t)HW * cpg <= (size_t)gn_small_max());   // gamma / beta: 8 KB of LDS at most
+  const size_t lim = (long)B * G >= 1536 ? (size_t)std::min(gn_small_max(), 8192) : (size_t)gn_small_max();
+  return (cpg % 4 == 0) && (C1 % 4 == 0) && cpg <= 1024 && ((size_t)HW * cpg <= lim);   // gamma / beta: 8 KB of LDS at most
 }
 static int launch_gn_small(const half_t* x1, const half_t* x2, int C1, int C2, int B, int HW, int G, float eps, const float* gamma,
                            const float* beta, int silu, half_t* out, hipStream_t st) {
@@ -348,7 +352,7 @@ int launch_groupnorm(const half_t* x1, const half_t* x2, int C1, int C2, int B, 
                      const float* beta, int silu, half_t* out, float* partial, hipStream_t st) {
   const int C = C1 + C2;
   if ((C & 7) || (C1 & 7) || C % G || G > 64) return -3;
-  if (gn_small_ok(C1, C2, HW, G)) return launch_gn_small(x1, x2, C1, C2, B, HW, G, eps, gamma, beta, silu, out, st);
+  if (gn_small_ok(C1, C2, HW, G, B)) return launch_gn_small(x1, x2, C1, C2, B, HW, G, eps, gamma, beta, silu, out, st);
   const int C8 = C >> 3;
   const int TC = C8 < 256 ? C8 : 256, TP = 256 / TC;
   const int nchunk = gn_nchunk(HW);
@@ -495,7 +499,7 @@ int launch_groupnorm_fused(const half_t* x1, const half_t* x2, int C1, int C2, i
   // the one-launch kernel runs one block per (sample, group) -- a few dozen blocks at one row -- yet measured equal to the
   // two-launch path there (5.72 vs 5.75 ms per forward): no threshold by default
   static const int small_min_blocks = getenv("PNPI_GN_SMALL_MIN") ? atoi(getenv("PNPI_GN_SMALL_MIN")) : 0;
-  if (gn_small_ok(C1, C2, HW, G) && B * G >= small_min_blocks)
+  if (gn_small_ok(C1, C2, HW, G, B) && B * G >= small_min_blocks)
     return launch_gn_small(x1, x2, C1, C2, B, HW, G, eps, gamma, beta, silu, out, st);
   if ((long)B * HW <= g_gn_inline_rows) {
     // ~2 blocks per CU, each with enough pixels to amortise its own reduction of the partials

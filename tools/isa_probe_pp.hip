@@ -5,4 +5,4 @@
 #ifndef PROBE_ARGS
 #define PROBE_ARGS 256, 256, 2, 4
 #endif
-template __global__ void igemm_pp_kernel<PROBE_ARGS>(GemmP, const half_t*);
+template __global__ void igemm_pp_kernel<PROBE_ARGS>(GemmP);
