@@ -495,7 +495,7 @@ def main():
                 name, targs = tag.split("<")
                 want = "%d%sI" % (len(name), name) + "".join("Li%sE" % a for a in targs.rstrip(">").split(",")) + "E"
                 for row in csv.DictReader(open(stats_csv)):
-                    if want in row["Name"]:
+                    if want in row["Name"] or tag in row["Name"].replace(" ", ""):       # mangled, or demangled "void igemm_pp_kernel<192, 320, 1, 4, 0>(GemmP)"
                         us = float(row["AverageNs"]) / 1e3
                         roofline["rocprof"] = {"avg_launch_us": us, "calls": int(row["Calls"]),
                                                "achieved": roofline["alg_flop_per_launch"] / us / 1e6,

@@ -14,7 +14,10 @@ from pnpinversion_amd.build import source_hash
 def template_of(mangled):
     """_Z15igemm_pp_kernelILi192ELi320ELi1ELi4ELi0EEv5GemmPPKDF16_ -> igemm_pp_kernel<192,320,1,4,0>"""
     m = re.match(r"_Z\d+(igemm_\w+?_kernel)I((?:Li\d+E)+)E", mangled)
-    return "%s<%s>" % (m.group(1), ",".join(re.findall(r"Li(\d+)E", m.group(2)))) if m else None
+    if m:
+        return "%s<%s>" % (m.group(1), ",".join(re.findall(r"Li(\d+)E", m.group(2))))
+    m = re.match(r"(?:void )?(igemm_\w+?_kernel)<([\d, ]+)>", mangled)       # rocprofv3 demangles the signatures it can: "void igemm_pp_kernel<192, 320, 1, 4, 0>(GemmP)"
+    return "%s<%s>" % (m.group(1), m.group(2).replace(" ", "")) if m else None
 
 
 def agg(fn, cn):
