@@ -110,3 +110,40 @@ def test_pixel_metrics_against_independent_implementations():
     panel = np.concatenate([a[:80], a[:80], b[:80], b[:80]], axis=1)
     rep = metrics.panel_report(panel, mask=m[:80, :, 0])
     assert set(rep) >= {"recon_psnr", "edit_ssim", "psnr_unedit_part"} and abs(rep["recon_mse"] - metrics.calculate_mse(b[:80], a[:80])) < 1e-12
+
+
+def test_proximal_guidance_forward_inversion_guidance_semantics(monkeypatch):
+    """models/p2p/proximal_guidance_forward.py:73 reads `mask_edit is not None and inversion_guidance and (recon_t > 0 and t < recon_t) or
+    (recon_t < 0 and t > -recon_t)`: the pull towards the inversion trajectory runs with the flag inside a positive recon_t window, and --
+    by `and` binding tighter than `or` -- ALWAYS inside a negative one.  Host logic only: what reaches the loop (the `recon` descriptor)."""
+    import pytest
+    import pnpinversion_amd.p2p.proximal_guidance_forward as pg
+    seen = {}
+
+    def fake_loop(**kw):
+        seen.clear(); seen.update(kw)
+        return "latents", "latent"
+
+    monkeypatch.setattr(pg, "p2p_guidance_forward", fake_loop)
+    xs, enc = ["x*0", "x*1", "x*2"], "encoded"
+    call = lambda **k: pg.proximal_guidance_forward(model=None, prompt=["a", "b"], controller=None, num_inference_steps=2, prox="l0", **k)
+    call(recon_lr=0.5, recon_t=400)                                                      # nothing to pull towards
+    assert seen["recon"] is None and seen["prox"] == "l0"
+    call(recon_lr=0.5, recon_t=400, x_stars=xs)                                          # positive window, flag off: x_stars is ignored
+    assert seen["recon"] is None
+    call(recon_lr=0.5, recon_t=400, x_stars=xs, inversion_guidance=True)
+    assert seen["recon"]["x_stars"] is xs and seen["recon"]["ref_image"] is None and seen["recon"]["recon_t"] == 400
+    call(recon_lr=0.5, recon_t=-600, x_stars=xs)                                         # negative window: the pull runs without the flag
+    assert seen["recon"]["x_stars"] is xs and seen["recon"]["recon_t"] == -600
+    call(recon_lr=0.5, recon_t=400, image_enc=enc)                                       # reconstruction guidance alone
+    assert seen["recon"]["ref_image"] == enc and seen["recon"]["x_stars"] is None
+    call(recon_lr=0.0, recon_t=400, image_enc=enc, x_stars=xs, inversion_guidance=True)  # recon_lr = 0 switches both off
+    assert seen["recon"] is None
+    call(recon_lr=0.5, recon_t=400, x_stars=xs, inversion_guidance=True, edit_stage=False)   # the reconstruction pass: no proximal step at all
+    assert seen["recon"] is None and seen["prox"] is None
+    with pytest.raises(ValueError, match="needs x_stars"):
+        call(recon_lr=0.5, recon_t=-600)
+    with pytest.raises(ValueError, match="needs x_stars"):
+        call(recon_lr=0.5, recon_t=400, inversion_guidance=True)
+    with pytest.raises(NotImplementedError):
+        pg.proximal_guidance_forward(model=None, prompt=["a", "b"], controller=None, num_inference_steps=2, prox="l2")
