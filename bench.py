@@ -187,13 +187,36 @@ def main():
 
     for i in range(args.warmup):
         one_edit(i)
+    # `clock` (rank 0): a fixed MFMA-only calibration kernel before and after the timed region (effective matrix-pipe GHz) and the part's
+    # own sclk / socket power / temperature sampled from a side thread during it -- so that a swing of the headline between boxes or
+    # rounds can be attributed from the record.  Both probes are OUTSIDE the timed region.
+    from pnpinversion_amd.utils.gpu_clock import ClockSampler
+
+    def mfma_probe():
+        try:
+            torch.cuda.synchronize()
+            ghz, ms = eng.clock_probe()
+            return {"effective_ghz": round(ghz, 4), "probe_ms": round(ms, 2)}
+        except Exception as e:      # the probe must never take the headline line down
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    clock = {"mfma_probe_before": mfma_probe()} if rank == 0 else None
+    sampler = ClockSampler(local_rank) if rank == 0 else None
     barrier()
     eng.reset_counters()
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for i in range(args.steps):
         panel = one_edit(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__(None, None, None)
+        clock["during_timed_region"] = sampler.summary()
+        clock["mfma_probe_after"] = mfma_probe()
+        clock["note"] = ("mfma_probe: v_mfma_f32_32x32x16_f16 back to back on every SIMD (pnpi_clock_probe, pseudo-random operands, HIP events): "
+                         "matrix-pipe cycles / elapsed; nominal 2.4 GHz.  during_timed_region: the part's own sensors, side thread")
     if dist is not None:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -521,7 +544,7 @@ def main():
             "bcast_ms": bcast.get("ms"), "bcast_mb": (bcast.get("bytes", 0) / 1e6) if bcast else None,   # the start-up weight broadcast (untimed set-up)
             "whole_path_tflops_per_gpu": per_rank_flops / dt / 1e12,
             "whole_path_mfma_frac": per_rank_flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
-            "roofline": roofline, "phases": phases,
+            "roofline": roofline, "phases": phases, "clock": clock,
         }
         if pruned is not None:
             out["pruned_schedule"] = pruned

@@ -177,6 +177,11 @@ typedef struct {
 int pnpi_profile_begin(pnpi_ctx* ctx);
 int pnpi_profile_end(pnpi_ctx* ctx, pnpi_kernel_stats* out /* [PNPI_KC_COUNT] */);
 
+/* Matrix-pipe clock calibration for bench.py's `clock` object (no reference counterpart: it protects the one number the driver times):
+ * every SIMD issues `iters` x 16 v_mfma_f32_32x32x16_f16 back to back (2 waves per SIMD, register operands, pseudo-random values), timed
+ * with HIP events on the ctx stream; *ghz_out = matrix-pipe cycles / elapsed = the clock the part holds under a pure MFMA load. */
+int pnpi_clock_probe(pnpi_ctx* ctx, int iters, float* ghz_out, float* ms_out /* nullable */);
+
 /* ---- level 1: operator boundary (keeps the loops under models/p2p/ usable unmodified) ---------------------------- */
 /* model.unet(latents, t, encoder_hidden_states=context)["sample"]    inversion.py:273, p2p_guidance_forward.py:109 */
 int pnpi_unet_forward(pnpi_ctx* ctx, const float* latents, int rows, int rows_per_image, int t, const float* context,

@@ -533,8 +533,13 @@ def proximal_inv_guidance(steps=4):
     np.savez_compressed(os.path.join(OUT, "proximal_inv_guidance.npz"), **out)
 
 
-def null_text(steps=3, cfg=SMALL64, seed=2, name="e2e_null_text"):
-    """cfg=SD1 (name e2e_null_text_sd1, 2 steps x 10 Adam iterations, weight seed 0): BASELINE config 4 at the benchmarked width.
+def null_text(steps=3, cfg=SMALL64, seed=2, name="e2e_null_text", keep_every=1, perturb=None):
+    """keep_every > 1 (round 6, e2e_null_text_sd1_20: 20 steps x 10 Adam iterations at full width): only every keep_every-th inversion
+    latent / optimised embedding (plus the end points) is stored.  perturb = (relative sigma, seed): the SAME reference run with every UNet
+    output multiplied by 1 + sigma * N(0, 1) (sigma = 2^-11: one fp16 rounding per UNet call, far less than any fp16-storage pipeline
+    incurs) -- the reference's own sensitivity at this schedule, stored beside the golden as the yardstick of the latent bar
+    (tests/test_gpu_sd1_configs.py), as tests/test_gpu_headline_parity.py does for the headline against the oracle.
+    cfg=SD1 (name e2e_null_text_sd1, 2 steps x 10 Adam iterations, weight seed 0): BASELINE config 4 at the benchmarked width.
     P2PEditor("null-text-inversion+p2p") of the reference (models/p2p_editor.py:199-259): NullInversion.invert = ddim_inversion +
     null_optimization (10 Adam iterations per step through the UNet w.r.t. the 77 x D unconditional embedding, inversion.py:196-234),
     then p2p_guidance_forward twice with the per-step embeddings.  Same image / prompts / weights / controller as e2e_refine.
@@ -571,6 +576,17 @@ def null_text(steps=3, cfg=SMALL64, seed=2, name="e2e_null_text"):
         return r
 
     pe.p2p_guidance_forward, inv.NullInversion.invert, inv.nnf.mse_loss = spy_fwd, spy_inv, spy_mse
+    hook = None
+    if perturb is not None:
+        sigma, pseed = perturb
+        gen = torch.Generator().manual_seed(pseed)
+
+        def noisy(_m, _a, out):
+            e = out["sample"]
+            out["sample"] = e * (1 + sigma * torch.randn(e.shape, generator=gen).to(e.dtype))
+            return out
+
+        hook = ed.ldm_stable.unet.register_forward_hook(noisy)
     try:
         with ref_shim.cuda_to_cpu():           # NOT under no_grad: null_optimization differentiates through the UNet
             panel = ed("null-text-inversion+p2p", image_path=img, prompt_src=src, prompt_tar=tgt, guidance_scale=7.5, cross_replace_steps=0.4,
@@ -578,8 +594,18 @@ def null_text(steps=3, cfg=SMALL64, seed=2, name="e2e_null_text"):
                        is_replace_controller=False)
     finally:
         pe.p2p_guidance_forward, inv.NullInversion.invert, inv.nnf.mse_loss = orig_fwd, orig_inv, orig_mse
+        if hook is not None:
+            hook.remove()
     assert len(calls) == 2
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_stars=stages["x_stars"], uncond_embeddings=stages["uncond"],
+    kept = {}
+    if keep_every > 1:
+        xs_idx = sorted(set(list(range(0, steps + 1, keep_every)) + [steps]))
+        un_idx = sorted(set(list(range(0, steps, keep_every)) + [steps - 1]))
+        stages["x_stars"], stages["uncond"] = stages["x_stars"][xs_idx], stages["uncond"][un_idx]
+        kept = dict(x_stars_index=np.array(xs_idx, np.int64), uncond_index=np.array(un_idx, np.int64))
+    if perturb is not None:
+        kept.update(perturb_sigma=np.float64(perturb[0]), perturb_seed=np.int64(perturb[1]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_stars=stages["x_stars"], uncond_embeddings=stages["uncond"], **kept,
                         context=stages["context"], losses=np.array(losses, dtype=np.float64), reconstruct_latent=calls[0],
                         edited_latents=calls[1], edited_image_small=np.array(panel)[::4, 3 * 512::4], steps=np.int64(steps), src=src, tgt=tgt,
                         blend=np.array([w0, w1]), weight_seed=np.int64(seed))
@@ -820,6 +846,18 @@ if __name__ == "__main__":
     if "null_text_sd1_5" in which:
         # round 5: the same at 5 steps x 10 Adam iterations (about 25 CPU-minutes): drift of the fp16 reverse walk / Adam state over more steps
         null_text(steps=5, cfg=SD1, seed=0, name="e2e_null_text_sd1_5")
+    if "null_text_sd1_20" in which:
+        # round 6: 20 steps x 10 Adam iterations at full width, every 5th latent / embedding kept
+        null_text(steps=20, cfg=SD1, seed=0, name="e2e_null_text_sd1_20", keep_every=5)
+    if "null_text_sd1_20_pert" in which:
+        # the same reference run with one fp16 rounding (relative 2^-11) on every UNet output: the reference's own sensitivity
+        null_text(steps=20, cfg=SD1, seed=0, name="e2e_null_text_sd1_20_pert", keep_every=5, perturb=(2.0 ** -11, 77))
+    if "null_text_sd1_5_pert" in which:
+        null_text(steps=5, cfg=SD1, seed=0, name="e2e_null_text_sd1_5_pert", perturb=(2.0 ** -11, 77))
+    if "e2e_sd1_replace" in which:
+        # round 6: BASELINE config 2's "P2P AttentionReplace" at the full SD-1.x width: the cake pair (equal word counts),
+        # is_replace_controller=True with LocalBlend + Reweight, 2 + 2 steps
+        e2e("sd1_replace", True, True, steps=2, cfg=SD1, seed=0)
     if "masactrl_sd1_10" in which:
         # round 5: 10 steps, mutual self-attention from step 3 (about 15 CPU-minutes)
         masactrl(steps=10, start_step=3, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_10")

@@ -76,6 +76,7 @@ SYMBOLS = {
     "pnpi_set_scheduler": (_i, [_vp, C.POINTER(C.c_float), _i, _f]),
     "pnpi_get_counters": (_i, [_vp, C.POINTER(Counters)]),
     "pnpi_reset_counters": (_i, [_vp]),
+    "pnpi_clock_probe": (_i, [_vp, _i, _fp, _fp]),
     "pnpi_profile_begin": (_i, [_vp]),
     "pnpi_profile_end": (_i, [_vp, C.POINTER(KernelStats)]),
     "pnpi_unet_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(CtrlDesc), _i, _vp]),

@@ -341,6 +341,58 @@ int pnpi_set_scheduler(pnpi_ctx* c, const float* ac, int n_train, float final_al
 int pnpi_get_counters(const pnpi_ctx* c, pnpi_counters* out) { if (!c || !out) return PNPI_EINVAL; *out = c->ctr; return 0; }
 int pnpi_reset_counters(pnpi_ctx* c) { if (!c) return PNPI_EINVAL; memset(&c->ctr, 0, sizeof(c->ctr)); return 0; }
 
+// Matrix-pipe clock calibration (bench.py's `clock` object): every SIMD of the chip issues v_mfma_f32_32x32x16_f16 back to back on register
+// operands with pseudo-random fp16 values (two waves per SIMD, four independent accumulators each): 32 matrix-pipe cycles per instruction
+// (MI355X_MICROARCH.md, "Per-instruction cycle constants"), so cycles / elapsed = the clock the part holds under a pure MFMA load.
+__global__ void __launch_bounds__(512, 2) mfma_clock_kernel(int iters, float* sink) {
+  const int lane = threadIdx.x & 63;
+  unsigned h = (unsigned)(blockIdx.x * 512 + threadIdx.x) * 2654435761u;
+  half8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13;
+    a[j] = (half_t)((float)(h & 0xffff) * (2.f / 65536.f) - 1.f);
+    b[j] = (half_t)((float)(h >> 16) * (2.f / 65536.f) - 1.f);
+  }
+  floatx16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  for (int t = 0; t < iters; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = mfma32(a, b, acc[i]);
+  }
+  float s_ = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s_ += acc[i][0] + acc[i][15];
+  if (s_ == 12345.678f) sink[blockIdx.x * 64 + lane] = s_;      // never true in practice: keeps the accumulators live
+}
+
+int pnpi_clock_probe(pnpi_ctx* c, int iters, float* ghz_out, float* ms_out) {
+  if (!c || iters <= 0 || iters > (1 << 24) || !ghz_out) return PNPI_EINVAL;
+  int dev = 0, cus = 0;
+  CKH(hipGetDevice(&dev));
+  CKH(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  hipEvent_t e0, e1;
+  CKH(hipEventCreate(&e0));
+  CKH(hipEventCreate(&e1));
+  CKH(hipEventRecord(e0, c->st));
+  hipLaunchKernelGGL(mfma_clock_kernel, dim3(cus), dim3(512), 0, c->st, iters, (float*)c->gn_partial);
+  CKH(hipGetLastError());
+  CKH(hipEventRecord(e1, c->st));
+  CKH(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CKH(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  // one workgroup of 8 waves per CU = 2 waves per SIMD, 16 MFMAs per wave and iteration, 32 pipe cycles each
+  *ghz_out = ms > 0.f ? (float)(2.0 * 16.0 * 32.0 * (double)iters / ((double)ms * 1e6)) : 0.f;
+  if (ms_out) *ms_out = ms;
+  return 0;
+}
+
 int pnpi_profile_begin(pnpi_ctx* c) {
   if (!c) return PNPI_EINVAL;
   CKH(hipStreamSynchronize(c->st));

@@ -214,6 +214,12 @@ class NativeEngine:
     def reset_counters(self):
         self._call("pnpi_reset_counters")
 
+    def clock_probe(self, iters=100000):
+        """effective matrix-pipe clock (GHz) under back-to-back MFMAs on every SIMD, and the probe's duration (ms)"""
+        ghz, ms = C.c_float(), C.c_float()
+        self._call("pnpi_clock_probe", int(iters), C.byref(ghz), C.byref(ms))
+        return float(ghz.value), float(ms.value)
+
     def profile_begin(self):
         self._call("pnpi_profile_begin")
 

@@ -60,8 +60,13 @@ def _cat_image():
 
 
 # ----------------------------------------------------------------------------------------------- (a) full SD-1.x width
-def test_sd1_full_width_loops_and_editor_against_reference_golden():
-    g = np.load(os.path.join(GOLD, "e2e_sd1.npz"))
+@pytest.mark.parametrize("fixture", ["e2e_sd1.npz", "e2e_sd1_replace.npz"])
+def test_sd1_full_width_loops_and_editor_against_reference_golden(fixture):
+    """e2e_sd1.npz: Refine + Reweight + LocalBlend (the PIE-Bench default).  e2e_sd1_replace.npz (round 6): BASELINE
+    config 2's "P2P AttentionReplace" -- is_replace_controller=True (the 77 x 77 replacement mapper of attention_control.py:301-314 in
+    attn_cross_edit_kernel at 320 / 640 / 1280 channels) + Reweight + LocalBlend on the cake pair, the reference's own run."""
+    g = np.load(os.path.join(GOLD, fixture))
+    is_replace = bool(g["is_replace"])
     cfg, steps = SD1, int(g["steps"])
     pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
     seed = int(g["weight_seed"])
@@ -76,8 +81,10 @@ def test_sd1_full_width_loops_and_editor_against_reference_golden():
     assert r_inv < 4e-3 * steps ** 0.5, r_inv
     src, tgt = str(g["src"]), str(g["tgt"])
     w0, w1 = [str(x) for x in g["blend"]]
-    ctrl = ac.make_controller(pipe, [src, tgt], False, {"default_": 0.4}, 0.6, ((w0,), (w1,)), {"words": (w1,), "values": (2,)},
+    ctrl = ac.make_controller(pipe, [src, tgt], is_replace, {"default_": 0.4}, 0.6, ((w0,), (w1,)), {"words": (w1,), "values": (2,)},
                               num_ddim_steps=steps)
+    inner = ctrl.prev_controller if isinstance(ctrl, ac.AttentionReweight) else ctrl
+    assert isinstance(inner, ac.AttentionReplace if is_replace else ac.AttentionRefine)
     # the product's schedule: offsets + reconstruction + edit pass, one 12-row launch per timestep, from the reference's trajectory
     nl, lats = eng.direct_edit(x_stars, ctx[None], [None, [ctrl.tables()]], ts, 7.5)
     r_nl = rel(nl[:, 0], g["noise_loss"])
@@ -91,7 +98,8 @@ def test_sd1_full_width_loops_and_editor_against_reference_golden():
     # drop-in API end to end at full width (VAE at 512 x 512 included): panels of the reference's own run, 4x subsampled
     ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=pipe)
     panel, st = ed.edit_image_directinversion(_cat_image(), src, tgt, guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
-                                              blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)}, return_stages=True)
+                                              blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)}, return_stages=True,
+                                              is_replace_controller=is_replace)
     xs = torch.stack([x.cpu() for x in st["x_stars"]])
     assert rel(xs, g["x_stars"]) < 6e-3, rel(xs, g["x_stars"])          # includes the full-width 512 x 512 VAE encode
     r_e2e, frac = masked_rel(st["latents"], torch.from_numpy(g["edited_latents"]))
