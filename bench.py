@@ -402,21 +402,27 @@ def main():
                                                       eq_params=[{"words": ("dog",), "values": (2,)}] * nb)
         batch_edit(0)
         barrier()
+        eng.reset_counters()
         tb = time.perf_counter()
         batch_edit(1)
         barrier()
         dtb = time.perf_counter() - tb
+        cb = eng.counters()             # the batched run's OWN executed FLOPs (text K / V rows and cached forwards differ from the one-image run)
         if dist is not None:
             tt = torch.tensor([dtb], device="cuda", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dtb = float(tt.item())
         batched = {"images_per_launch_set_per_gpu": nb, "value": nb * world / dtb, "unit": "images/s", "ms_per_batch": dtb * 1e3,
-                   "whole_path_mfma_frac": nb * (per_image_flops_faithful() / dtb) / 1e12 / MFMA_PEAK_TFLOPS,
+                   "whole_path_mfma_frac": executed_flops(cb) / dtb / 1e12 / MFMA_PEAK_TFLOPS,
+                   "unet_sample_forwards_per_image": cb["unet_sample_forwards"] / nb,
                    "note": "BASELINE config 3's launch shape (batch = %d per GPU): same faithful schedule per image; %d-row inversion launches, "
                            "%d-row lock-step launches" % (nb, nb, 12 * nb)}
         if rank == 0:
             # the same loop north_star's 40 % target is stated on, at config 3's batch: 50 steps of one 12 nb-row launch set
-            batched["phases"] = loop_phases(lambda: batch_edit(1), nb)
+            try:
+                batched["phases"] = loop_phases(lambda: batch_edit(1), nb)
+            except Exception as e:   # an extra must never take the headline line down
+                batched["phases"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # extra (never `value`): sweep throughput with the NEXT image's inversion on a second context / HIP stream under this image's
     # lock-step loop (P2PEditor.edit_stream_directinversion); same kernels, same panels

@@ -114,6 +114,8 @@ typedef struct {
  * the (shrunk) CFG difference is not above the proximal threshold:  mask_edit = dilate(|delta| > thr, kernel 2*dilate_mask+1);
  * pred_x0 -= recon_lr * (pred_x0 - ref_image) * (1 - mask_edit).  Only meaningful with prox != 0. */
 typedef struct {
+  uint32_t struct_size;            /* = sizeof(pnpi_recon_desc), set by the caller: the struct grew a field in round 5 and may grow again; an
+                                      entry point answers any other value with PNPI_EINVAL instead of reading past what the caller filled */
   const float* ref_image;          /* device [nimg][4][h][w]: image_enc_latent (0.18215 * VAE posterior mean of the source image) */
   float recon_lr;
   int recon_t;
@@ -121,7 +123,9 @@ typedef struct {
   /* inversion guidance (proximal_guidance_forward.py:73-75): inv_x_stars = the inversion trajectory x*_0 .. x*_nsteps, device fp32
    * [nsteps+1][nimg][4][h][w] (nullable = off); at step i inside the recon_t window the step's result is pulled towards
    * x*_{nsteps-1-i} outside the edit mask with recon_lr.  ref_image may then be NULL (no pred-x0 pull).  pnpi_cfg_ddim_prev (level 1,
-   * one step, no step index): inv_x_stars points at THIS step's x*_{t-1}, [nimg][4][h][w]. */
+   * one step, no step index): inv_x_stars points at THIS step's x*_{t-1}, [nimg][4][h][w].
+   * recon_lr: the pred-x0 pull runs for recon_lr > 0 only (scheduler_dev.py:68), the inversion pull for any recon_lr != 0 (the
+   * reference applies `latents - recon_lr * (...)` unconditionally inside the window, proximal_guidance_forward.py:75). */
   const float* inv_x_stars;
 } pnpi_recon_desc;
 
@@ -297,8 +301,9 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
 /* process-wide kernel tuning knobs: variant A/B inside one process (tools/fwd_ab.py, tools/fwd_tune.py) and tests of non-default
  * variants; PNPI_EINVAL for an unknown key.  They are plain process globals read by every context's launches: set them while no other
  * thread is inside a pnpi_* call (the product never calls this; several contexts on several threads -- P2PEditor.edit_stream_in_flight --
- * only READ them).  "igemm_vpp" / "igemm_sched" / "igemm_v128" = 11, 12, 15 need a library built with `build.py --ablations`
- * (-DPNPI_ABLATIONS=1); the product library answers them with an argument error at the launch.  "gn_slab" (0): 1 = a split-K launch whose
+ * only READ them).  A non-zero "igemm_vpp" / "igemm_sched" and "igemm_v128" / "igemm_v320" = 11, 12, 15 select ablation instances
+ * that exist only in a library built with `python -m pnpinversion_amd.build --ablations` (-DPNPI_ABLATIONS=1 -> csrc/libpnpi_ablations.so,
+ * loaded with PNPI_LIBRARY=<path>); the product library REJECTS those values here with PNPI_EINVAL.  "gn_slab" (0): 1 = a split-K launch whose
  * output goes to a small-map GroupNorm leaves its combine to that kernel (bit-identical, measured slower: profiles/round5_gn_slab_ab.txt).
  * Keys (default): "text_kv" (1) / "temb_cache" (1) per-loop caches; "gn_inline_rows" (0)
  * one-launch GroupNorm below this many rows; "igemm_dma" (1) LDS-DMA kernel family; "igemm_table" (1) measured tile table before the

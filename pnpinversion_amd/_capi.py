@@ -40,7 +40,12 @@ class CtrlDesc(C.Structure):
 
 
 class ReconDesc(C.Structure):
-    _fields_ = [("ref_image", C.c_void_p), ("recon_lr", C.c_float), ("recon_t", C.c_int), ("dilate_mask", C.c_int), ("inv_x_stars", C.c_void_p)]
+    _fields_ = [("struct_size", C.c_uint32), ("ref_image", C.c_void_p), ("recon_lr", C.c_float), ("recon_t", C.c_int), ("dilate_mask", C.c_int),
+                ("inv_x_stars", C.c_void_p)]
+
+    @classmethod
+    def make(cls, ref_image, recon_lr, recon_t, dilate_mask=0, inv_x_stars=None):
+        return cls(C.sizeof(cls), ref_image, float(recon_lr), int(recon_t), int(dilate_mask), inv_x_stars)
 
 
 ATTN_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
@@ -150,7 +155,7 @@ def load_library(path=None):
     # torch ships its own libamdhip64; it must be the first (and only) HIP runtime mapped into the process, otherwise this
     # library would initialise a second runtime that sees no device.
     import torch  # noqa: F401
-    p = path or LIB_PATH
+    p = path or os.environ.get("PNPI_LIBRARY") or LIB_PATH      # PNPI_LIBRARY: e.g. csrc/libpnpi_ablations.so for tools/pp_ablate.py
     if not os.path.exists(p):
         raise ImportError(
             "libpnpi.so not found at %s -- build it with `python -m pnpinversion_amd.build` (hipcc, gfx950). "
@@ -165,7 +170,8 @@ def load_library(path=None):
     for kv in filter(None, os.environ.get("PNPI_TUNE", "").split(",")):
         k, v = kv.split("=")
         if lib.pnpi_set_tuning(k.strip().encode(), int(v)) != 0:
-            raise ValueError("PNPI_TUNE: unknown tuning key %r" % k)
+            raise ValueError("PNPI_TUNE: unknown tuning key %r, or a value this build does not carry (ablation selectors need "
+                             "`python -m pnpinversion_amd.build --ablations` + PNPI_LIBRARY)" % k)
     if path is None:
         _lib = lib
     return lib

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libpnpi.so")
+LIB_ABLATIONS = os.path.join(CSRC, "libpnpi_ablations.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "step.hip", "bwd.hip", "api.hip"]
 HEADERS = ["common.h", "ops.h", "model.h", "tile_table.inc", "igemm_dma.inc", "igemm_pp.inc", "api_weights.inc", "api_graph.inc", "api_backward.inc", "api_vae.inc", "api_ctrl.inc", os.path.join("..", "..", "include", "pnpi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-value"]
@@ -49,7 +50,11 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True, ablations=False):
     """ablations: also compile the kernel instances that leave out the MFMAs / the DMA / the fragment reads (tools/pp_ablate.py,
-    tools/profile_pp.sh, tuning igemm_vpp / igemm_sched / igemm_v128 = 11, 12, 15) -- not part of the product library."""
+    tools/profile_pp.sh, tuning igemm_vpp / igemm_sched / igemm_v128 = 11, 12, 15) -- not part of the product library: they go to their
+    own object directory and their own library, csrc/libpnpi_ablations.so (load it with PNPI_LIBRARY=<path>), so the product .so is
+    never overwritten by an ablation build."""
+    OBJ = os.path.join(CSRC, "build_ablations" if ablations else "build")
+    LIB = LIB_ABLATIONS if ablations else globals()["LIB"]
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -93,4 +98,4 @@ if __name__ == "__main__":
     if "--source-hash" in sys.argv:
         print(source_hash())
     else:
-        build(force="--force" in sys.argv or "--ablations" in sys.argv, ablations="--ablations" in sys.argv)
+        print(build(force="--force" in sys.argv, ablations="--ablations" in sys.argv))

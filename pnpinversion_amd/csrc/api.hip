@@ -584,8 +584,16 @@ int pnpi_ddim_prev_step_recon(pnpi_ctx* c, const float* eps, int t, int ratio, c
   CK(launch_ddim_prev_recon(sample, eps, af, at, on ? ref_image : nullptr, recon_lr, on ? recon_mask : nullptr, n, out, pred_x0_out, c->st));
   return 0;
 }
-static bool recon_active(const pnpi_recon_desc* rc, int t) {   // proximal_guidance_forward.py:48,60 (and :73 for the inversion pull)
-  return rc && (rc->ref_image || rc->inv_x_stars) && rc->recon_lr > 0.f && ((rc->recon_t > 0 && t < rc->recon_t) || (rc->recon_t < 0 && t > -rc->recon_t));
+// the recon_t window of proximal_guidance_forward.py:48,60 (and :73 for the inversion pull).  Inside it the pred-x0 pull towards ref_image
+// runs for recon_lr > 0 (scheduler_dev.py:68), the pull of the step's result towards x*_{t-1} for any recon_lr != 0 (:75 has no such test)
+static bool recon_window(const pnpi_recon_desc* rc, int t) {
+  return rc && ((rc->recon_t > 0 && t < rc->recon_t) || (rc->recon_t < 0 && t > -rc->recon_t));
+}
+static const float* recon_ref_at(const pnpi_recon_desc* rc, int t) { return (recon_window(rc, t) && rc->recon_lr > 0.f) ? rc->ref_image : nullptr; }
+static bool recon_inv_at(const pnpi_recon_desc* rc, int t) { return recon_window(rc, t) && rc->inv_x_stars && rc->recon_lr != 0.f; }
+static int recon_check(pnpi_ctx* c, const pnpi_recon_desc* rc) {
+  if (rc && rc->struct_size != (uint32_t)sizeof(pnpi_recon_desc)) return fail(c, PNPI_EINVAL, "pnpi_recon_desc.struct_size is not sizeof(pnpi_recon_desc) of this library");
+  return 0;
 }
 
 int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, int rpi, size_t row_elems, float gs, int t, int ratio,
@@ -593,11 +601,13 @@ int pnpi_cfg_ddim_prev(pnpi_ctx* c, const float* eps, const float* x, int nimg, 
                        float* x_out, const float* prox_threshold, int prox, const pnpi_recon_desc* recon) {
   if (prox < 0 || prox > 2 || (prox && !prox_threshold)) return fail(c, PNPI_EINVAL, "prox must be 0, or 1 / 2 with a threshold");
   float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
-  const bool rc = prox && recon_active(recon, t);
+  CKP(recon_check(c, recon));
+  const float* rref = prox ? recon_ref_at(recon, t) : nullptr;
+  const float* rinv = (prox && recon_inv_at(recon, t)) ? recon->inv_x_stars : nullptr;     // level 1: the caller points inv_x_stars at this step's x*_{t-1} [nimg][...]
+  const bool rc = rref || rinv;
   const int S = c->cfg.sample_size;
   CK(launch_cfg_ddim_prev(eps, x, nimg, rpi, row_elems, gs, af, at, noise_loss, offset_rows, target, offset_scale, offset_out, x_out, c->st,
-                          prox_threshold, prox, rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, S, S,
-                          rc ? recon->inv_x_stars : nullptr));        // level 1: the caller points inv_x_stars at this step's x*_{t-1} [nimg][...]
+                          prox_threshold, prox, rref, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, S, S, rinv));
   return 0;
 }
 
@@ -786,6 +796,7 @@ static int edit_loop_impl(pnpi_ctx* c, const float* x_T, int nimg, const float* 
                           const pnpi_ctrl_desc* ctrl_host, int nsteps, const int* ts, float gs, int prox, float quantile,
                           const pnpi_recon_desc* recon, float* latents_out, const float* uncond_steps, int uncond_first_only) {
   if (!c || !x_T || !context4 || !ts || !latents_out || nsteps <= 0) return PNPI_EINVAL;
+  CKP(recon_check(c, recon));
   CKP(check_loop_ready(c));
   const pnpi_model_config& g = c->cfg;
   const size_t E = (size_t)g.in_channels * g.sample_size * g.sample_size;
@@ -832,12 +843,12 @@ static int edit_loop_impl(pnpi_ctx* c, const float* x_T, int nimg, const float* 
     float af, at; CKP(alphas_for(c, t, ratio, false, &af, &at));
     const float* nl = noise_loss ? noise_loss + (size_t)i * nimg * 2 * E : nullptr;
     if (prox && quantile > 0.f) CK(launch_quantile_abs_diff(eps, nimg, 2, E, quantile, thr, c->st));
-    const bool rc = prox && recon_active(recon, t);
+    const float* rref = prox ? recon_ref_at(recon, t) : nullptr;
     // inversion guidance: x_stars[len(x_stars) - i - 2] (proximal_guidance_forward.py:75), one latent per image for both of its rows
-    const float* inv = (rc && recon->inv_x_stars) ? recon->inv_x_stars + (size_t)(nsteps - 1 - i) * nimg * E : nullptr;
+    const float* inv = (prox && recon_inv_at(recon, t)) ? recon->inv_x_stars + (size_t)(nsteps - 1 - i) * nimg * E : nullptr;
+    const bool rc = rref || inv;
     CK(launch_cfg_ddim_prev(eps, lat, nimg, 2, E, gs, af, at, nl, offset_rows, nullptr, 1.f, nullptr, lat, c->st, prox ? thr : nullptr, prox,
-                            rc ? recon->ref_image : nullptr, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, g.sample_size,
-                            g.sample_size, inv));
+                            rref, rc ? recon->recon_lr : 0.f, rc ? recon->dilate_mask : 0, g.sample_size, g.sample_size, inv));
     if (use_ctrl) CKP(apply_local_blend(c, lat, i));
   }
   CKH(hipMemcpyAsync(latents_out, lat, (size_t)nimg * 2 * E * sizeof(float), hipMemcpyDeviceToDevice, c->st));

@@ -414,6 +414,12 @@ void igemm_set_dma(int on) { g_use_dma = on; }
 int igemm_set_tuning(const char* key, int v) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_use_dma}, {"igemm_v128", &g_var128}, {"igemm_v64", &g_var64}, {"igemm_v256", &g_var256},
                                              {"igemm_v320", &g_var320}, {"igemm_v256n", &g_var256n}, {"igemm_wide", &g_wide}, {"tile_order", &g_tile_order}, {"igemm_force_cfg", &g_force_cfg}, {"igemm_force_split", &g_force_split}, {"igemm_bias_init", &g_bias_init}, {"igemm_sched", &g_sched}, {"igemm_vpp", &g_varpp}, {"igemm_tapin", &g_tapin}, {"igemm_pp_only_n", &g_pp_only_n}, {"igemm_pp_only_k", &g_pp_only_k}, {"igemm_pp_only_m", &g_pp_only_m}, {"igemm_deep_rings", &g_deep_rings}, {"igemm_vt_lds", &g_vt_lds}, {"igemm_res_late", &g_res_late}, {"igemm_table", &g_use_table}, {"igemm_table_near", &g_table_near}};
+#ifndef PNPI_ABLATIONS
+  // the ablation instances (no MFMAs / no DMA / no fragment reads, the hand-scheduled 4-wave loop) exist only in a `build --ablations`
+  // library: a product build rejects their selectors here instead of silently timing the default kernel
+  if ((!strcmp(key, "igemm_sched") || !strcmp(key, "igemm_vpp")) && v != 0) return -2;
+  if ((!strcmp(key, "igemm_v128") || !strcmp(key, "igemm_v320")) && (v == 11 || v == 12 || v == 15)) return -2;
+#endif
   for (auto& e : tab)
     if (!strcmp(key, e.k)) { *e.p = v; return 0; }
   return -1;

@@ -414,8 +414,8 @@ class NativeEngine:
             xs = torch.stack([x for x in xs]) if isinstance(xs, (list, tuple)) else xs
             inv = self._f32(xs).reshape(nsteps + 1, -1, *xT.shape[1:])
             inv = inv.expand(nsteps + 1, nimg, *xT.shape[1:]).contiguous()
-        rd = _capi.ReconDesc(ref.data_ptr() if ref is not None else None, float(recon["recon_lr"]), int(recon["recon_t"]),
-                             int(recon.get("dilate_mask") or 0), inv.data_ptr() if inv is not None else None)
+        rd = _capi.ReconDesc.make(ref.data_ptr() if ref is not None else None, recon["recon_lr"], recon["recon_t"],
+                                  int(recon.get("dilate_mask") or 0), inv.data_ptr() if inv is not None else None)
         return rd, (ref, inv)
 
     def edit_loop_uncond_steps(self, x_T, context4, uncond_steps, ctrls, timesteps, guidance_scale, first_only=False, prox=None, quantile=0.7,

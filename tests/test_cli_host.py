@@ -141,6 +141,21 @@ def test_proximal_guidance_forward_inversion_guidance_semantics(monkeypatch):
     assert seen["recon"] is None
     call(recon_lr=0.5, recon_t=400, x_stars=xs, inversion_guidance=True, edit_stage=False)   # the reconstruction pass: no proximal step at all
     assert seen["recon"] is None and seen["prox"] is None
+    # recon_lr < 0: the pred-x0 pull is off (scheduler_dev.py:68 tests recon_lr > 0), the inversion pull is not (line 75 has no test)
+    call(recon_lr=-0.5, recon_t=400, image_enc=enc, x_stars=xs, inversion_guidance=True)
+    assert seen["recon"]["ref_image"] is None and seen["recon"]["x_stars"] is xs and seen["recon"]["recon_lr"] == -0.5
+    call(recon_lr=-0.5, recon_t=400, image_enc=enc)
+    assert seen["recon"] is None
+    # a negative recon_t without a proximal step: the reference reaches `1 - mask_edit` with mask_edit = None at the first step with t > -recon_t
+    from types import SimpleNamespace as NS
+    mdl = NS(scheduler=NS(config=NS(num_train_timesteps=1000, steps_offset=0), num_inference_steps=2))
+    with pytest.raises(TypeError, match="mask_edit = None"):
+        pg.proximal_guidance_forward(model=mdl, prompt=["a", "b"], controller=None, num_inference_steps=2, prox="l0", recon_t=-400, x_stars=xs,
+                                     edit_stage=False)
+    with pytest.raises(TypeError, match="mask_edit = None"):
+        pg.proximal_guidance_forward(model=mdl, prompt=["a", "b"], controller=None, num_inference_steps=2, prox=None, recon_t=-400, x_stars=xs)
+    pg.proximal_guidance_forward(model=mdl, prompt=["a", "b"], controller=None, num_inference_steps=2, prox=None, recon_t=-600, x_stars=xs)   # t = 500, 0: never > 600
+    assert seen["recon"] is None and seen["prox"] is None
     with pytest.raises(ValueError, match="needs x_stars"):
         call(recon_lr=0.5, recon_t=-600)
     with pytest.raises(ValueError, match="needs x_stars"):

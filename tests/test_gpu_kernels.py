@@ -718,6 +718,52 @@ def test_proximal_step_bit_exact(ctx, prox):
         assert torch.equal(xo.cpu(), want), (xo.cpu() - want).abs().max()
 
 
+@pytest.mark.parametrize("lr", [0.1, -0.25])
+@pytest.mark.parametrize("with_ref", [False, True])
+def test_inversion_guidance_step_bit_exact(ctx, with_ref, lr):
+    """Level 1 of the inversion pull (ADVICE r5): pnpi_cfg_ddim_prev with pnpi_recon_desc::inv_x_stars pointing at THIS step's x*_{t-1}
+    -- prev - recon_lr * (prev - x*) * (1 - mask_edit) (proximal_guidance_forward.py:73-75) on top of the optional pred-x0 pull, bit for bit
+    against the torch formulas; the pred-x0 pull needs recon_lr > 0 (scheduler_dev.py:68), the inversion pull does not; inert outside the
+    recon_t window; a descriptor whose struct_size is not this library's is refused."""
+    from oracle import p2p_oracle as po
+    from pnpinversion_amd import _capi
+    g = torch.Generator().manual_seed(21)
+    S = ctx.cfg.sample_size
+    eps = torch.randn(4, 4, S, S, generator=g)
+    x = torch.randn(2, 4, S, S, generator=g)
+    ref = torch.randn(1, 4, S, S, generator=g)
+    xstar = torch.randn(1, 4, S, S, generator=g)
+    ac, ratio, dil = po.alphas_cumprod(), 20, 1
+    ctx.call("pnpi_set_scheduler", (C.c_float * 1000)(*ac.tolist()), 1000, float(ac[0]))
+    ed, xd, rd, sd_ = eps.cuda(), x.cuda(), ref.cuda(), xstar.cuda()
+    thr_d = torch.empty(1, device="cuda")
+    ctx.call("pnpi_prox_threshold", ptr(ed), 1, 2, x[0].numel(), 0.75, ptr(thr_d))
+    thr = thr_d.cpu()[0]
+    d = eps[2:] - eps[:2]
+    sd = d - d.clamp(-thr, thr)
+    e = eps[:2] + 7.5 * sd
+    recon_mask = 1 - F.max_pool2d((sd.abs() > thr).float(), 2 * dil + 1, 1, dil)
+    desc = _capi.ReconDesc.make(rd.data_ptr() if with_ref else None, lr, 400, dil, sd_.data_ptr())
+    for t, active in ((381, True), (401, False)):
+        xo = torch.empty_like(xd)
+        ctx.call("pnpi_cfg_ddim_prev", ptr(ed), ptr(xd), 1, 2, x[0].numel(), 7.5, t, ratio, None, 0, None, 1.0, None, ptr(xo),
+                 ptr(thr_d), 1, C.byref(desc))
+        a_t, a_p = po.prev_alphas(ac, ac[0], t, ratio)
+        sa_f, sb_f, sa_t, sb_t = po._scalars(float(a_t), float(a_p), torch.float32)
+        x0 = (x - sb_f * e) / sa_f
+        if active and with_ref and lr > 0:
+            x0 = x0 - lr * (x0 - ref.expand_as(x0)) * recon_mask
+        want = sa_t * x0 + sb_t * e
+        if active:
+            want = want - lr * (want - xstar.expand_as(want)) * recon_mask          # both rows of the image towards the one x*_{t-1}
+        assert torch.equal(xo.cpu(), want), (t, (xo.cpu() - want).abs().max())
+    bad = _capi.ReconDesc.make(None, lr, 400, dil, sd_.data_ptr())
+    bad.struct_size = 32                                                             # e.g. a caller compiled against the four-field struct
+    with pytest.raises(_capi.PnpiError, match="struct_size"):
+        ctx.call("pnpi_cfg_ddim_prev", ptr(ed), ptr(xd), 1, 2, x[0].numel(), 7.5, 381, ratio, None, 0, None, 1.0, None, ptr(xo),
+                 ptr(thr_d), 1, C.byref(bad))
+
+
 @pytest.mark.parametrize("dil", [0, 1, 2])
 @pytest.mark.parametrize("prox", ["l0", "l1"])
 def test_reconstruction_guidance_step_bit_exact(ctx, prox, dil):
@@ -747,7 +793,7 @@ def test_reconstruction_guidance_step_bit_exact(ctx, prox, dil):
     if dil > 0:
         mask_edit = F.max_pool2d(mask_edit, 2 * dil + 1, 1, dil)
     recon_mask = 1 - mask_edit
-    desc = _capi.ReconDesc(rd.data_ptr(), lr, 400, dil)
+    desc = _capi.ReconDesc.make(rd.data_ptr(), lr, 400, dil)
     for t, active in ((381, True), (401, False)):
         xo = torch.empty_like(xd)
         ctx.call("pnpi_cfg_ddim_prev", ptr(ed), ptr(xd), 1, 2, x[0].numel(), 7.5, t, ratio, None, 0, None, 1.0, None, ptr(xo),

@@ -708,6 +708,57 @@ def test_inversion_guidance_against_reference_golden(small64, name, monkeypatch)
     small64.scheduler.set_timesteps(2)
 
 
+@pytest.mark.parametrize("case", ["pos_flag", "neg_window", "neg_lr", "with_ref"])
+def test_inversion_guidance_loop_step_by_step_exact(small64, case):
+    """Deterministic pin of the loop-level inversion guidance (the golden-based test above tolerates mask flips): the SAME device
+    UNet (level 1, on the text K / V cache as the loop) drives an fp32 torch restatement of proximal_guidance_forward.py:39-79 step by
+    step -- quantile threshold, l0 shrink, dilated mask, optional pred-x0 pull, DDIM step, pull of BOTH rows towards
+    x_stars[len(x_stars) - i - 2] -- and pnpi_edit_loop must land on the same latents bit for bit.  x_stars are distinct random latents, so a
+    wrong index, a one-row pull or a shifted recon_t window cannot pass."""
+    import torch.nn.functional as F
+    eng = small64.engine
+    cfg = eng.cfg
+    steps = 4
+    small64.scheduler.set_timesteps(steps)
+    ts = small64.scheduler.timesteps.numpy()
+    ratio = 1000 // steps
+    g = torch.Generator().manual_seed(91)
+    S = cfg.sample_size
+    zT = torch.randn(1, 4, S, S, generator=g)
+    xs = torch.randn(steps + 1, 1, 4, S, S, generator=g)
+    enc = torch.randn(1, 4, S, S, generator=g)
+    ctx = weights.synth_context(cfg, 4, seed=92)
+    lr, recon_t, ref = {"pos_flag": (0.5, 400, None), "neg_window": (0.5, -600, None), "neg_lr": (-0.25, 400, None),
+                        "with_ref": (0.5, 400, enc)}[case]
+    q, dil, gs = 0.75, 1, 7.5
+    out = eng.edit_loop(zT, ctx[None], None, None, ts, gs, prox="l0", quantile=q,
+                        recon=dict(ref_image=ref, recon_lr=lr, recon_t=recon_t, dilate_mask=dil, x_stars=xs))[0].cpu()
+    ac_ = po.alphas_cumprod()
+    eng.text_kv_precompute(ctx)
+    lat = zT.expand(2, -1, -1, -1).clone()
+    pulls = 0
+    for i, t in enumerate(int(v) for v in ts):
+        eps = eng.unet(torch.cat([lat, lat]), t, None).cpu()
+        d = eps[2:] - eps[:2]
+        thr = d.abs().quantile(q)
+        sd = d - d.clamp(-thr, thr)
+        e = eps[:2] + gs * sd
+        a_t, a_p = po.prev_alphas(ac_, ac_[0], t, ratio)
+        sa_f, sb_f, sa_t, sb_t = po._scalars(float(a_t), float(a_p), torch.float32)
+        x0 = (lat - sb_f * e) / sa_f
+        window = (recon_t > 0 and t < recon_t) or (recon_t < 0 and t > -recon_t)
+        recon_mask = 1 - F.max_pool2d((sd.abs() > thr).float(), 2 * dil + 1, 1, dil)
+        if window and ref is not None and lr > 0:
+            x0 = x0 - lr * (x0 - ref.expand_as(x0)) * recon_mask
+        lat = sa_t * x0 + sb_t * e
+        if window:
+            lat = lat - lr * (lat - xs[len(xs) - i - 2].expand_as(lat)) * recon_mask
+            pulls += 1
+    assert pulls == (1 if case == "neg_window" else 2)
+    assert torch.equal(out, lat), (case, (out - lat).abs().max().item())
+    small64.scheduler.set_timesteps(2)
+
+
 def test_masactrl_driver_cli(tmp_path, capsys):
     """run_editing_masactrl.py end to end (both methods, native CLIP text encoder) on a 2-image PIE-Bench-shaped directory."""
     import json
