@@ -363,15 +363,21 @@ class P2PEditor:
                                latents=latents, reconstruct_image=reconstruct_image, edited_image=images[-1])
         return panel
 
-    def _second_pipeline(self):
+    def _second_pipeline(self, rows=4):
         """A second library context on its own HIP stream, borrowing the main context's packed weight arena (pnpi_create_shared): the inversion of
-        the NEXT image runs there while this image's lock-step loop runs on the main context."""
-        if getattr(self, "_inverter", None) is None:
+        the NEXT image (rows = 4) or of the next BATCH of images (rows = images per batch) runs there while this one's lock-step loop runs
+        on the main context."""
+        inverter = getattr(self, "_inverter", None)
+        if inverter is not None and inverter.engine.max_unet_rows < rows:       # a wider batch than the context was built for: rebuild it
+            torch.cuda.synchronize(self.ldm_stable.device)
+            inverter.engine.close()
+            inverter = self._inverter = None
+        if inverter is None:
             main = self.ldm_stable
             torch.cuda.synchronize(main.device)
             self._inv_stream = torch.cuda.Stream(device=main.device)
             with torch.cuda.device(main.device), torch.cuda.stream(self._inv_stream):
-                p = main.peer(max_unet_rows=4, max_vae_images=2)
+                p = main.peer(max_unet_rows=max(4, rows), max_vae_images=2)
                 self._inv_stream.synchronize()
                 p.scheduler.set_timesteps(self.num_ddim_steps)
             self._inverter = p
@@ -505,11 +511,18 @@ class P2PEditor:
         launches, the three 4-row passes of every image as one 12n-row launch per timestep.  Images are independent rows in
         every kernel; per-image results equal the single-image call within the fp16 tolerance (tests/test_gpu_loops.py).
         blend_words / eq_params: None or one entry per image.  Returns the list of 4-panel images."""
-        model, eng = self.ldm_stable, self.ldm_stable.engine
+        st1 = self._batch_invert_stage(self.ldm_stable, image_paths, prompts_src, prompts_tar)
+        return self._batch_edit_stage(st1, prompts_src, prompts_tar, guidance_scale, cross_replace_steps, self_replace_steps, blend_words,
+                                      eq_params, is_replace_controller, add_target, return_stages)
+
+    def _batch_invert_stage(self, model, image_paths, prompts_src, prompts_tar):
+        """Stage 1 of a batch on `model` (the main pipeline, or the second context of `edit_stream_images_directinversion`): load, prompt
+        embedding, VAE encode (+ the reference's discarded decode, inversion.py:357), the 50 n-row inversion steps."""
+        eng = model.engine
         n = len(image_paths)
         if not (len(prompts_src) == len(prompts_tar) == n):
             raise ValueError("image_paths, prompts_src and prompts_tar must have the same length")
-        if eng.max_unet_rows < 12 * n:
+        if self.ldm_stable.engine.max_unet_rows < 12 * n or eng.max_unet_rows < n:
             raise ValueError(f"batch of {n} images needs a pipeline built with max_unet_rows >= {12 * n}")
         side = eng.cfg.sample_size * eng.cfg.vae_scale
         images_gt = []
@@ -521,22 +534,34 @@ class P2PEditor:
         model.scheduler.set_timesteps(self.num_ddim_steps)
         ts = model.scheduler.timesteps.numpy()
         inv = DirectInversion(model=model, num_ddim_steps=self.num_ddim_steps)
-        contexts, controllers = [], []
+        contexts = []
         register_attention_control(model, None)
         for i in range(n):
-            prompts = [prompts_src[i], prompts_tar[i]]
-            inv.init_prompt(prompts)
+            inv.init_prompt([prompts_src[i], prompts_tar[i]])
             contexts.append(inv.context)
-            controllers.append(make_controller(pipeline=model, prompts=prompts, is_replace_controller=is_replace_controller,
+        ctx = torch.stack(contexts)                                        # [n, 4, 77, 768]
+        z0 = image2latent(model.vae, np.stack(images_gt))                  # [n, 4, h, w]
+        latent2image(model.vae, z0)                                        # the reference's discarded image_rec decode (inversion.py:357)
+        x_stars = eng.ddim_invert(z0, ctx[:, 2], ts)                       # [steps+1, n, 4, h, w]
+        return images_gt, side, ctx, x_stars
+
+    def _batch_edit_stage(self, st1, prompts_src, prompts_tar, guidance_scale, cross_replace_steps, self_replace_steps, blend_words,
+                          eq_params, is_replace_controller, add_target, return_stages):
+        """Stage 2 on the main pipeline: controllers, the 12n-row lock-step loop from the inversion trajectories, the decodes, the panels."""
+        images_gt, side, ctx, x_stars = st1
+        model, eng = self.ldm_stable, self.ldm_stable.engine
+        n = len(images_gt)
+        model.scheduler.set_timesteps(self.num_ddim_steps)
+        ts = model.scheduler.timesteps.numpy()
+        register_attention_control(model, None)
+        controllers = []
+        for i in range(n):
+            controllers.append(make_controller(pipeline=model, prompts=[prompts_src[i], prompts_tar[i]], is_replace_controller=is_replace_controller,
                                                cross_replace_steps={"default_": cross_replace_steps},
                                                self_replace_steps=self_replace_steps,
                                                blend_words=blend_words[i] if blend_words is not None else None,
                                                equilizer_params=eq_params[i] if eq_params is not None else None,
                                                num_ddim_steps=self.num_ddim_steps, device=self.device))
-        ctx = torch.stack(contexts)                                        # [n, 4, 77, 768]
-        z0 = image2latent(model.vae, np.stack(images_gt))                  # [n, 4, h, w]
-        latent2image(model.vae, z0)                                        # the reference's discarded image_rec decode (inversion.py:357)
-        x_stars = eng.ddim_invert(z0, ctx[:, 2], ts)                       # [steps+1, n, 4, h, w]
         nl, lats = eng.direct_edit(x_stars, ctx, [None, [c.tables() for c in controllers]], ts, guidance_scale,
                                    offset_rows=2 if add_target else 1)
         for c in controllers:
@@ -550,3 +575,37 @@ class P2PEditor:
         if return_stages:
             return panels, dict(x_stars=x_stars, noise_loss=nl, reconstruct_latents=lats[0], latents=lats[1])
         return panels
+
+    def edit_stream_images_directinversion(self, batches, guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
+                                           is_replace_controller=False):
+        """`edit_images_directinversion` over a sequence of BATCHES with stage overlap (BASELINE config 3's launch shape: batch = 8 per GPU):
+        while batch i runs its 50 lock-step steps of 12n rows on the main context, batch i + 1's prompt embeddings, VAE encodes and 50
+        n-row inversion steps run on the second context / HIP stream from a worker thread -- what `edit_stream_directinversion` does for
+        single images.  Same kernels on the same inputs as `edit_images_directinversion` batch by batch -> identical panels
+        (tests/test_gpu_sd1_extras.py); only sweep throughput changes (run_editing_p2p.py:102-146 visits images one by one).
+        batches: iterable of (image_paths, prompts_src, prompts_tar, blend_words | None, eq_params | None).  Generator of panel lists."""
+        from concurrent.futures import ThreadPoolExecutor
+        batches = list(batches)
+        if not batches:
+            return
+        main = self.ldm_stable
+        inverter = self._second_pipeline(rows=max(len(b[0]) for b in batches))
+
+        def stage1(b):
+            with torch.no_grad(), torch.cuda.device(main.device), torch.cuda.stream(self._inv_stream):
+                images_gt, side, ctx, x = self._batch_invert_stage(inverter, b[0], b[1], b[2])
+                ctx, x = ctx.clone(), x.clone()
+                self._inv_stream.synchronize()          # the consumer is another stream: hand over finished tensors
+            return images_gt, side, ctx, x
+
+        with ThreadPoolExecutor(max_workers=1) as ex, torch.no_grad():
+            fut = ex.submit(stage1, batches[0])
+            for i, b in enumerate(batches):
+                st1 = fut.result()
+                for t in st1[2:]:
+                    if t.is_cuda:                        # produced on the worker's stream, consumed on this one
+                        t.record_stream(torch.cuda.current_stream(main.device))
+                if i + 1 < len(batches):
+                    fut = ex.submit(stage1, batches[i + 1])
+                yield self._batch_edit_stage(st1, b[1], b[2], guidance_scale, cross_replace_steps, self_replace_steps,
+                                             b[3] if len(b) > 3 else None, b[4] if len(b) > 4 else None, is_replace_controller, False, False)

@@ -103,6 +103,29 @@ def test_sd1_batched_images_against_reference_golden(sd1, n):
         assert rel(st["latents"][i], st["latents"][0]) < 1e-6
 
 
+def test_sd1_batched_stream_overlaps_the_next_batch_inversion_with_identical_panels(sd1):
+    """bench.py `batched.pipelined` (round 6): batches of 4 images, the next batch's 4-row inversion on a second context /
+    HIP stream under this batch's 48-row lock-step loop -- the same kernels on the same inputs as the serial batch call -> identical
+    panels; and those within the bars of the reference's own run."""
+    pipe, g = sd1
+    src, tgt, blend, eq = _kw(g)
+    ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=int(g["steps"]), pipeline=pipe)
+    img, n = _cat_image(), 4
+    kw = dict(guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6)
+    imgs = [np.roll(img, 17 * j, axis=1) for j in range(n)]                          # different images per row (image 0 is the golden's)
+    serial = [np.array(p) for p in ed.edit_images_directinversion(imgs, [src] * n, [tgt] * n, blend_words=[blend] * n, eq_params=[eq] * n, **kw)]
+    _check_panel(serial[0], g, "serial batch, image 0")
+    batch = (imgs, [src] * n, [tgt] * n, [blend] * n, [eq] * n)
+    try:
+        got = [[np.array(p) for p in panels] for panels in ed.edit_stream_images_directinversion([batch] * 3, **kw)]
+    finally:
+        ed.close_peers()
+    assert len(got) == 3 and all(len(b) == n for b in got)
+    for bi, b in enumerate(got):
+        for i in range(n):
+            assert np.array_equal(b[i], serial[i]), "overlapped batch %d: image %d differs from the serial batch's panel" % (bi, i)
+
+
 def test_sd1_pruned_schedule_against_reference_golden(sd1):
     """bench.py `pruned_schedule`: 3-row launches (source latent assigned from the inversion trajectory) at full width."""
     pipe, g = sd1
