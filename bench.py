@@ -517,12 +517,12 @@ def main():
         if roofline is not None:
             roofline["source_sha16"] = sha
             tag = roofline["kernel"].replace(" ", "")           # igemm_pp_kernel<192,320,1,4,0>
-            rounds = ("round5", "round4")
+            rounds = ("round6", "round5", "round4")
             cand = [os.path.join(prof, "%s_pmc_traffic_bench.json" % r) for r in rounds]
             have = [(c_, json.load(open(c_))) for c_ in cand if os.path.exists(c_)]
             match = [(c_, j_) for c_, j_ in have if j_.get("source_sha16") == sha]
             if not have:
-                roofline["traffic_note"] = "no committed counter summary (profiles/round5_pmc_traffic_bench.json)"
+                roofline["traffic_note"] = "no committed counter summary (profiles/round6_pmc_traffic_bench.json)"
             elif not match:
                 roofline["traffic_note"] = "%s was measured on kernel sources %s, this tree is %s: not reported" % (
                     os.path.relpath(have[0][0], os.path.dirname(prof)), have[0][1].get("source_sha16"), sha)

@@ -71,3 +71,13 @@ def test_committed_bench_line_honours_the_contract():
         assert bp["lockstep_rows"] == 12 * nb and bp["inversion_rows"] == nb
         lf = 50 * 12 * nb * (UNET_GFLOP - TEXT_KV_GFLOP) * 1e9 + 12 * nb * TEXT_KV_GFLOP * 1e9
         assert abs(bp["lockstep_loop_mfma_frac"] - lf / (bp["lockstep_loop_ms"] * 1e-3) / 1e12 / PEAK) < 1e-3 * bp["lockstep_loop_mfma_frac"]
+    if "round6" in os.path.basename(path) or d.get("clock"):      # round 6: the clock the number was measured at travels with it
+        ck = d["clock"]
+        for probe in ("mfma_probe_before", "mfma_probe_after"):
+            assert 0.5 < ck[probe]["effective_ghz"] <= 2.45 and ck[probe]["probe_ms"] > 1.0, ck[probe]
+        dur = ck["during_timed_region"]
+        assert "source" in dur and "samples" in dur
+        if dur["source"] is not None:
+            assert dur["samples"] >= 1 and 100.0 < dur["sclk_mhz"]["mean"] <= 2500.0 and dur["sclk_mhz"]["min"] <= dur["sclk_mhz"]["mean"] <= dur["sclk_mhz"]["max"]
+        if "pipelined" in b:
+            assert b["pipelined"].get("error") or (b["pipelined"]["unit"] == "images/s" and b["pipelined"]["value"] > 0)
