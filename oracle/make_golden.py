@@ -858,6 +858,9 @@ if __name__ == "__main__":
         # round 6: BASELINE config 2's "P2P AttentionReplace" at the full SD-1.x width: the cake pair (equal word counts),
         # is_replace_controller=True with LocalBlend + Reweight, 2 + 2 steps
         e2e("sd1_replace", True, True, steps=2, cfg=SD1, seed=0)
+    if "e2e_sd1_replace_50" in which:
+        # the same at the benchmarked SCHEDULE: 50 + 50 steps (about an hour of CPU), every 10th inversion latent / offset kept
+        e2e("sd1_replace_50", True, True, steps=50, cfg=SD1, seed=0, keep_every=10)
     if "masactrl_sd1_10" in which:
         # round 5: 10 steps, mutual self-attention from step 3 (about 15 CPU-minutes)
         masactrl(steps=10, start_step=3, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_10")

@@ -128,11 +128,16 @@ def _subsampled_stage_errors(st, g, steps):
     return inv, off
 
 
-def test_sd1_full_width_full_schedule_against_reference_golden():
+@pytest.mark.parametrize("fixture", ["e2e_sd1_50.npz", "e2e_sd1_replace_50.npz"])
+def test_sd1_full_width_full_schedule_against_reference_golden(fixture):
     """The benchmarked configuration at the benchmarked schedule: the reference's own P2PEditor("directinversion+p2p") at full SD-1.x
     width, 50 + 50 steps, Refine + Reweight + LocalBlend (tests/golden/e2e_sd1_50.npz: 63 min of the build container's CPU, every 10th
-    inversion latent / offset kept) against the product's P2PEditor on the same image, prompts and weights.  Bars: SURVEY 8(d)."""
-    g = np.load(os.path.join(GOLD, "e2e_sd1_50.npz"))
+    inversion latent / offset kept) against the product's P2PEditor on the same image, prompts and weights.  Bars: SURVEY 8(d).
+    e2e_sd1_replace_50.npz (round 6): the same with is_replace_controller=True -- BASELINE config 2's "P2P AttentionReplace" -- on the cake pair."""
+    if not os.path.exists(os.path.join(GOLD, fixture)):
+        pytest.skip("%s not generated (oracle/make_golden.py %s)" % (fixture, fixture[:-4]))
+    g = np.load(os.path.join(GOLD, fixture))
+    is_replace = bool(g["is_replace"])
     cfg, steps = SD1, int(g["steps"])
     assert steps == 50
     pipe = NativePipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
@@ -142,7 +147,8 @@ def test_sd1_full_width_full_schedule_against_reference_golden():
     w0, w1 = [str(x) for x in g["blend"]]
     ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=pipe)
     panel, st = ed.edit_image_directinversion(_cat_image(), src, tgt, guidance_scale=7.5, cross_replace_steps=0.4, self_replace_steps=0.6,
-                                              blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)}, return_stages=True)
+                                              blend_word=((w0,), (w1,)), eq_params={"words": (w1,), "values": (2,)}, return_stages=True,
+                                              is_replace_controller=is_replace)
     inv, off = _subsampled_stage_errors(st, g, steps)
     rec, out = st["reconstruct_latent"].cpu(), st["latents"].cpu()
     g_rec, g_out = torch.from_numpy(g["reconstruct_latent"]), torch.from_numpy(g["edited_latents"])
@@ -158,7 +164,7 @@ def test_sd1_full_width_full_schedule_against_reference_golden():
            "final_reconstruction_target_rel_l2": r_rec, "final_edit_rel_l2": rel(out[1], g_out[1]), "final_edit_rel_l2_outside_localblend_flips": r_out,
            "localblend_mask_flip_fraction": frac, "edit_latent_rms": scale, "panel_mean_abs_diff": d, "panel_psnr_db": ps}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "drift_sd1_full_width_50.json"), "w"), indent=1)
+    json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "drift_sd1_full_width_50%s.json" % ("_replace" if is_replace else "")), "w"), indent=1)
     print("sd1 full width 50+50 vs the reference:", json.dumps(rep))
     for k, r in inv.items():
         assert r < 4e-3 * max(k, 1) ** 0.5, (k, r)                       # DDIM latents after k steps: <= 4e-3 sqrt(k)
