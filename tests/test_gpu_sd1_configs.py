@@ -134,6 +134,8 @@ def test_null_text_editor_full_width_against_reference_golden(fixture):
     assert r_unc < k("uncond", 1e-2), (r_unc, sens)
     assert l_dev < k("loss_max_dev", 2e-2), (l_dev, sens)
     assert r_rec < k("reconstruct", 2e-2) and r_edit < k("edited_src", 2e-2), (r_rec, r_edit, sens)
+    if sens is not None:       # the edited (target) row: its own sensitivity (at 2 steps, without a sensitivity run, it stays a logged figure as before)
+        assert r_edit_t < k("edited_tgt", 2e-2), (r_edit_t, sens)
     assert d_img <= 2.0, d_img
     pipe.engine.close()
 
