@@ -700,7 +700,7 @@ def null_text_family(steps=3):
     print("null_text_family %.1fs" % (time.time() - t0), {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
-def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e2e_masactrl"):
+def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e2e_masactrl", keep_every=1):
     """cfg=SD1 (name e2e_masactrl_sd1, 4 steps, mutual self-attention from step 1, weight seed 0): BASELINE config 5 at the benchmarked width.
     run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -754,6 +754,13 @@ def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e
             inv.DirectInversion.invert = orig_invert
             ed.model.invert = orig_pinv
         lat = [x for x in decoded if x.shape[0] in (1, 2) and x.ndim == 4]
+        if keep_every > 1:          # the 50-step fixture: every keep_every-th inversion latent / offset and the end points
+            xs_idx = sorted(set(list(range(0, steps + 1, keep_every)) + [steps]))
+            nl_idx = sorted(set(list(range(0, steps, keep_every)) + [steps - 1]))
+            out["x_stars_index"], out["noise_loss_index"] = np.array(xs_idx, np.int64), np.array(nl_idx, np.int64)
+            stages["x_stars"] = stages["x_stars"][xs_idx]
+            if "noise_loss" in stages:
+                stages["noise_loss"] = stages["noise_loss"][nl_idx]
         out[m + "/x_stars"] = stages["x_stars"]
         if "noise_loss" in stages:
             out[m + "/noise_loss"] = stages["noise_loss"]
@@ -864,6 +871,9 @@ if __name__ == "__main__":
     if "masactrl_sd1_10" in which:
         # round 5: 10 steps, mutual self-attention from step 3 (about 15 CPU-minutes)
         masactrl(steps=10, start_step=3, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_10")
+    if "masactrl_sd1_50" in which:
+        # round 6: BASELINE config 5 at the benchmarked schedule -- 50 steps, the editor's defaults (mutual self-attention from step 4 in blocks 10..15)
+        masactrl(steps=50, start_step=4, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_50", keep_every=10)
     if "masactrl_lists" in which:
         masactrl_lists()
     if "null_latent" in which or not sys.argv[1:]:

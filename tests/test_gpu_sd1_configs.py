@@ -140,11 +140,14 @@ def test_null_text_editor_full_width_against_reference_golden(fixture):
     pipe.engine.close()
 
 
-@pytest.mark.parametrize("fixture", ["e2e_masactrl_sd1.npz", "e2e_masactrl_sd1_10.npz"])       # 4 steps from step 1 (round 4); 10 steps from step 3 (round 5)
+# 4 steps from step 1 (round 4); 10 steps from step 3 (round 5); the benchmarked schedule: 50 steps, the editor's defaults (step 4, layer 10; round 6)
+@pytest.mark.parametrize("fixture", ["e2e_masactrl_sd1.npz", "e2e_masactrl_sd1_10.npz", "e2e_masactrl_sd1_50.npz"])
 @pytest.mark.parametrize("method", ["directinversion+masactrl", "ddim+masactrl"])
 def test_masactrl_editor_full_width_against_reference_golden(method, fixture):
     from pnpinversion_amd.masactrl.diffuser_utils import MasaCtrlPipeline
     from run_editing_masactrl import MasaCtrlEditor
+    if not os.path.exists(os.path.join(GOLD, fixture)):
+        pytest.skip("%s not generated (oracle/make_golden.py)" % fixture)
     g = np.load(os.path.join(GOLD, fixture))
     cfg, steps, seed = SD1, int(g["steps"]), int(g["weight_seed"])
     pipe = MasaCtrlPipeline(cfg, max_unet_rows=12, max_vae_images=2, text_encoder=SyntheticTextEncoder(cfg.cross_dim, seed=7))
@@ -154,10 +157,15 @@ def test_masactrl_editor_full_width_against_reference_golden(method, fixture):
     panel, st = fn(_cat_image(), str(g["src"]), str(g["tgt"]), 7.5, step=int(g["start_step"]), layper=int(g["start_layer"]), return_stages=True)
     assert panel.size == (2048, 512)
     xs = torch.stack([x.cpu() for x in st["x_stars"]])
+    sub = "x_stars_index" in g                                     # the 50-step fixture keeps every 10th latent / offset and the end points
+    if sub:
+        xs = xs[[int(i) for i in g["x_stars_index"]]]
     r_xs = rel(xs, g[method + "/x_stars"])
     out = {"x_stars": r_xs}
     if method + "/noise_loss" in g:
         nl = torch.stack([x.cpu() for x in st["noise_loss_list"]])
+        if sub:
+            nl = nl[[int(i) for i in g["noise_loss_index"]]]
         out["noise_loss"] = rel(nl, g[method + "/noise_loss"])
     p = np.array(panel)
     rec_small, edit_small = p[::4, 1024:1536:4], p[::4, 1536::4]
@@ -166,7 +174,7 @@ def test_masactrl_editor_full_width_against_reference_golden(method, fixture):
     if "latents" in st:
         out["masactrl_latents"] = rel(st["latents"], g[method + "/masactrl_latents"])
     print("full-width %s:" % method, out)
-    _log(method if fixture == "e2e_masactrl_sd1.npz" else method + "_10_steps", out)
+    _log(method if fixture == "e2e_masactrl_sd1.npz" else method + "_%d_steps" % steps, out)
     assert r_xs < 4e-3 * steps ** 0.5, r_xs
     if "noise_loss" in out:
         assert out["noise_loss"] < 2e-2, out["noise_loss"]
