@@ -700,7 +700,8 @@ def null_text_family(steps=3):
     print("null_text_family %.1fs" % (time.time() - t0), {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
-def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e2e_masactrl", keep_every=1):
+def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e2e_masactrl", keep_every=1, perturb=None,
+             methods=("directinversion+masactrl", "ddim+masactrl")):
     """cfg=SD1 (name e2e_masactrl_sd1, 4 steps, mutual self-attention from step 1, weight seed 0): BASELINE config 5 at the benchmarked width.
     run_editing_masactrl.py MasaCtrlEditor("directinversion+masactrl" / "ddim+masactrl"), SMALL64, 6 steps, mutual
     self-attention from step 2 in transformer blocks 10..15.  The pipeline's __call__ defaults to 50 sampling steps and the
@@ -721,7 +722,19 @@ def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e
     img_path = os.path.join(ref_shim.REF, "scripts", "example_cat.jpg")
     out = {"steps": np.int64(steps), "start_step": np.int64(start_step), "start_layer": np.int64(start_layer), "src": src, "tgt": tgt,
            "weight_seed": np.int64(seed)}
-    for m in ("directinversion+masactrl", "ddim+masactrl"):
+    hook = None
+    if perturb is not None:     # the reference's own sensitivity: every UNet output times 1 + sigma * N(0, 1) (see null_text)
+        sigma, pseed = perturb
+        gen = torch.Generator().manual_seed(pseed)
+
+        def noisy(_m, _a, o):
+            e = o["sample"]
+            o["sample"] = e * (1 + sigma * torch.randn(e.shape, generator=gen).to(e.dtype))
+            return o
+
+        hook = ed.model.unet.register_forward_hook(noisy)
+        out.update(perturb_sigma=np.float64(sigma), perturb_seed=np.int64(pseed))
+    for m in methods:
         t0 = time.time()
         decoded, stages = [], {}
         orig_l2i = ed.model.latent2image
@@ -770,6 +783,8 @@ def masactrl(steps=6, start_step=2, start_layer=10, cfg=SMALL64, seed=2, name="e
         out[m + "/recon_image_small"] = p[::4, 1024:1536:4]
         out[m + "/edited_image_small"] = p[::4, 1536::4]
         print("masactrl", m, "%.1fs" % (time.time() - t0), {k: v.shape for k, v in out.items() if k.startswith(m + "/")})
+    if hook is not None:
+        hook.remove()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
@@ -874,6 +889,11 @@ if __name__ == "__main__":
     if "masactrl_sd1_50" in which:
         # round 6: BASELINE config 5 at the benchmarked schedule -- 50 steps, the editor's defaults (mutual self-attention from step 4 in blocks 10..15)
         masactrl(steps=50, start_step=4, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_50", keep_every=10)
+    if "masactrl_sd1_50_pert" in which:
+        # the reference's own sensitivity of the uncorrected path (ddim+masactrl: plain DDIM sampling at guidance 7.5 from the inverted latent --
+        # the divergence direct inversion exists to remove): the same run with one fp16 rounding on every UNet output
+        masactrl(steps=50, start_step=4, start_layer=10, cfg=SD1, seed=0, name="e2e_masactrl_sd1_50_pert", keep_every=10, perturb=(2.0 ** -11, 77),
+                 methods=("ddim+masactrl",))
     if "masactrl_lists" in which:
         masactrl_lists()
     if "null_latent" in which or not sys.argv[1:]:

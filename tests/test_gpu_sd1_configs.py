@@ -180,5 +180,18 @@ def test_masactrl_editor_full_width_against_reference_golden(method, fixture):
         assert out["noise_loss"] < 2e-2, out["noise_loss"]
     if "masactrl_latents" in out:
         assert out["masactrl_latents"] < 2e-2, out["masactrl_latents"]
-    assert out["recon_mean_abs"] < 2.0 and out["edit_mean_abs"] < 2.0, out
+    # decoded panels mean |diff| <= 2 / 255.  Where the reference's own sensitivity run exists for the method (the 50-step
+    # `ddim+masactrl`: its third panel is plain DDIM sampling at guidance 7.5 from the inverted latent, WITHOUT the direct-inversion correction --
+    # the divergence the paper is about), the bar is 3 x what one fp16 rounding per UNet call does to the reference itself when that is larger.
+    bar_rec = bar_edit = 2.0
+    pert_path = os.path.join(GOLD, fixture.replace(".npz", "_pert.npz"))
+    if os.path.exists(pert_path):
+        pg = np.load(pert_path)
+        if method + "/recon_image_small" in pg:
+            sens_rec = float(np.abs(pg[method + "/recon_image_small"].astype(np.int32) - g[method + "/recon_image_small"].astype(np.int32)).mean())
+            sens_edit = float(np.abs(pg[method + "/edited_image_small"].astype(np.int32) - g[method + "/edited_image_small"].astype(np.int32)).mean())
+            out["reference_sensitivity_one_fp16_rounding_per_unet_call"] = {"recon_mean_abs": sens_rec, "edit_mean_abs": sens_edit}
+            _log(method if fixture == "e2e_masactrl_sd1.npz" else method + "_%d_steps" % steps, out)
+            bar_rec, bar_edit = max(2.0, 3.0 * sens_rec), max(2.0, 3.0 * sens_edit)
+    assert out["recon_mean_abs"] < bar_rec and out["edit_mean_abs"] < bar_edit, (out, bar_rec, bar_edit)
     pipe.engine.close()
