@@ -103,6 +103,36 @@ def test_sd1_batched_images_against_reference_golden(sd1, n):
         assert rel(st["latents"][i], st["latents"][0]) < 1e-6
 
 
+def test_sd1_batched_images_full_schedule_against_reference_golden(sd1):
+    """BASELINE config 3's launch shape at the benchmarked SCHEDULE (round 6): 8 copies of the golden's image through one set of launches --
+    50 eight-row inversion forwards, 50 ninety-six-row lock-step forwards -- against the reference's own 50 + 50-step run (e2e_sd1_50.npz) at
+    the bars of tests/test_gpu_headline_parity.py: what `bench.py`'s `batched` extra times."""
+    pipe, _ = sd1
+    g = np.load(os.path.join(GOLD, "e2e_sd1_50.npz"))
+    steps, n = int(g["steps"]), 8
+    assert steps == 50
+    src, tgt, blend, eq = _kw(g)
+    ed = P2PEditor(["directinversion+p2p"], "cuda", num_ddim_steps=steps, pipeline=pipe)
+    img = _cat_image()
+    panels, st = ed.edit_images_directinversion([img] * n, [src] * n, [tgt] * n, guidance_scale=7.5, cross_replace_steps=0.4,
+                                                self_replace_steps=0.6, blend_words=[blend] * n, eq_params=[eq] * n, return_stages=True)
+    xi = [int(i) for i in g["x_stars_index"]]
+    gx, go, gr = torch.from_numpy(g["x_stars"]), torch.from_numpy(g["edited_latents"]), torch.from_numpy(g["reconstruct_latent"])
+    for i in (0, n - 1):
+        for j, k in enumerate(xi):
+            r = rel(st["x_stars"][k, i].cpu(), gx[j, 0])
+            assert r < 4e-3 * max(k, 1) ** 0.5, (i, k, r)
+        assert rel(st["latents"][i][0], go[0]) < 2e-2                              # the source branch returns to x*_0
+        assert rel(st["reconstruct_latents"][i][1], gr[1]) < 2e-2
+        scale = max(1.0, float(go[1].pow(2).mean().sqrt()))
+        r_e, frac = masked_rel(st["latents"][i][1], go[1], pix_tol=0.25 * scale)
+        assert frac <= 0.005 and r_e < 2e-2, (i, r_e, frac)
+        _check_panel(panels[i], g, "batched n=8, 50 + 50 steps, image %d" % i)
+    for i in range(1, n):
+        assert rel(st["latents"][i], st["latents"][0]) < 1e-6                       # independent rows: every copy lands on the same latents
+    pipe.scheduler.set_timesteps(int(np.load(os.path.join(GOLD, "e2e_sd1.npz"))["steps"]))
+
+
 def test_sd1_batched_stream_overlaps_the_next_batch_inversion_with_identical_panels(sd1):
     """bench.py `batched.pipelined` (round 6): batches of 4 images, the next batch's 4-row inversion on a second context /
     HIP stream under this batch's 48-row lock-step loop -- the same kernels on the same inputs as the serial batch call -> identical
