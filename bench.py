@@ -558,6 +558,18 @@ def main():
                                                          "--warmup 1 --no-extras --no-cpu-baseline` (faithful edits only; same kernel sources, %s)" % (r, sha)}
                         break
                 break
+        # the same fractions against what the matrix pipes of THIS box sustain (information only; `frac` stays against the nominal peak):
+        # nominal peak x (MFMA-only probe clock / 2.4 GHz nominal)
+        try:
+            ghz = [clock[k]["effective_ghz"] for k in ("mfma_probe_before", "mfma_probe_after") if "effective_ghz" in clock.get(k, {})]
+            if ghz and roofline is not None:
+                sustained = MFMA_PEAK_TFLOPS * (sum(ghz) / len(ghz)) / 2.4
+                roofline["peak_at_mfma_probe_clock"] = sustained
+                roofline["frac_of_peak_at_mfma_probe_clock"] = roofline["achieved"] / sustained
+                if phases is not None:
+                    phases["lockstep_loop_frac_of_peak_at_mfma_probe_clock"] = phases["lockstep_loop_tflops"] / sustained
+        except Exception:
+            pass
         n_img = args.steps * world
         per_rank_flops = executed_flops(ctr)
         out = {
