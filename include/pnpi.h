@@ -303,7 +303,8 @@ int pnpi_op_conv_stats(pnpi_ctx* ctx, const void* x1_nhwc_f16, const void* x2_nh
  * thread is inside a pnpi_* call (the product never calls this; several contexts on several threads -- P2PEditor.edit_stream_in_flight --
  * only READ them).  A non-zero "igemm_vpp" / "igemm_sched" and "igemm_v128" / "igemm_v320" = 11, 12, 15 select ablation instances
  * that exist only in a library built with `python -m pnpinversion_amd.build --ablations` (-DPNPI_ABLATIONS=1 -> csrc/libpnpi_ablations.so,
- * loaded with PNPI_LIBRARY=<path>); the product library REJECTS those values here with PNPI_EINVAL.  "gn_slab" (0): 1 = a split-K launch whose
+ * loaded with PNPI_LIBRARY=<path>); the product library REJECTS those values here with PNPI_EINVAL -- and "attn_pipe" = 1 / 2 (round 6: the
+ * half-tile software-pipelined forms of the 64-wide flash kernel, measured slower) likewise.  "gn_slab" (0): 1 = a split-K launch whose
  * output goes to a small-map GroupNorm leaves its combine to that kernel (bit-identical, measured slower: profiles/round5_gn_slab_ab.txt).
  * Keys (default): "text_kv" (1) / "temb_cache" (1) per-loop caches; "gn_inline_rows" (0)
  * one-launch GroupNorm below this many rows; "igemm_dma" (1) LDS-DMA kernel family; "igemm_table" (1) measured tile table before the

@@ -1028,6 +1028,7 @@ int pnpi_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gn_inline_rows")) { norm_set_tuning_gn_inline_rows(value); return 0; }
   if (!strcmp(key, "attn_vt_perm")) { g_vt_perm = value; return 0; }
   if (!strcmp(key, "attn_aug")) { g_attn_aug = value; return 0; }
+  if (!strcmp(key, "attn_pipe")) return attn_set_tuning_pipe(value) == 0 ? 0 : PNPI_EINVAL;
   if (!strcmp(key, "gn_slab")) { g_gn_slab = value; return 0; }
   if (!strcmp(key, "op_attention_aug")) { g_op_attention_aug = value; return 0; }
   if (!strcmp(key, "op_attention_vt_perm")) { g_op_attention_vt_perm = value; return 0; }

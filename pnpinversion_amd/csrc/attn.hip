@@ -422,6 +422,191 @@ __global__ void __launch_bounds__(256) attn_flash_dma64_kernel(AttnP p) {
   }
 }
 
+#ifdef PNPI_ABLATIONS      // `python -m pnpinversion_amd.build --ablations` only: a measured-and-not-kept arm, kept reproducible (profiles/README.md, round 6)
+// EXPERIMENT (round 6, tuning "attn_pipe" = 1 / 2): attn_flash_dma64_kernel<true, 3, true> software-pipelined at HALF-tile
+// granularity inside each wave.  A 64-key tile is two 32-key halves; in half g the wave issues the three S' = K Q'^T MFMAs of half g + 1
+// (independent of everything else in the half), exponentiates the scores of half g and issues the four V^T P MFMAs of half g -- so that the
+// quarter-rate v_exp_f32 stream sits between MFMAs of its OWN instruction stream (the only place the matrix pipe and the VALU of a SIMD
+// overlap: tools/micro/mfma_valu_overlap) without holding a second full tile of scores (16 + 16 score registers = today's 32).  The
+// reference-point test of the AUG form runs per half; a change is applied before the next half's scores are issued, so nothing computed
+// ahead needs a correction.  K and V^T tiles ride separate two-slot rings: K(it) is read in halves 2it - 1 and 2it, V^T(it) in 2it and
+// 2it + 1, so K(it + 2) is requested at the top of half 2it + 1 and V^T(it + 2) at the top of half 2it + 2, each two halves before its
+// first read; one counted vmcnt + one barrier per half.
+// the placement of one half's main block: every MFMA followed by its share of the half's VALU work (16 v_exp_f32, 8 v_cvt_pk, the
+// maximum chain of the next half's scores), the fragment reads ahead of their MFMAs.  Masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read.
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define PIPE_SCHED()                                                     \
+  do {                                                                   \
+    SGB(0x100, 3);                                                       \
+    SGB(0x008, 1); SGB(0x002, 4);                                        \
+    SGB(0x008, 1); SGB(0x002, 4);                                        \
+    SGB(0x008, 1); SGB(0x100, 2); SGB(0x002, 6);                         \
+    SGB(0x008, 1); SGB(0x100, 2); SGB(0x002, 5);                         \
+    SGB(0x008, 1); SGB(0x002, 5);                                        \
+    SGB(0x008, 1); SGB(0x002, 5);                                        \
+    SGB(0x008, 1); SGB(0x002, 8);                                        \
+  } while (0)
+template <int PLACE>      // 0: the compiler's own schedule of the half; 1: the sched_group_barrier placement above
+__global__ void __launch_bounds__(256) attn_flash_pipe64_kernel(AttnP p) {
+  constexpr int DP = 64;
+  constexpr int KT = 64 * 128;          // one K tile or one V^T tile, bytes
+  __shared__ __attribute__((aligned(1024))) char smem[4 * KT];      // [K slot 0 | V slot 0 | K slot 1 | V slot 1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ql = lane & 31;
+  const int nqt = (p.Nq + 127) >> 7, T = nqt * p.heads * p.nrows, per = (T + 7) >> 3;
+  const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tix >= T) return;
+  const int qt = tix % nqt, head = (tix / nqt) % p.heads;
+  const int* rw = p.rows + (tix / (nqt * p.heads)) * 4;
+  const int orow = rw[0], qrow = rw[1], krow = rw[2], vrow = rw[3];
+  const int qtok = qt * 128 + wave * 32 + ql;
+  const bool qok = qtok < p.Nq;
+  half8 qf[3];
+  {
+    const half_t* qp = p.q + ((size_t)qrow * p.Nq + (qok ? qtok : 0)) * p.ldq + p.q_off + head * DP + h * 8;
+    const float c = p.scale * 1.44269504088896340736f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      qf[ks] = qok ? ldg_half8(qp + ks * 16) : zero_half8();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * c);
+    }
+  }
+  floatx16 O[2];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[ot][r] = 0.f;
+  float mrun = 0.f;
+  const half_t* kptr[2];
+  const half_t* vptr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave * 2 + i;
+    const int line = 4 * (j & 1) + (lane >> 4);
+    const int R = (j >> 1) * 16 + ((lane >> 3) & 1) * 8 + line;
+    const int ch = (lane & 7) ^ line;
+    kptr[i] = p.k + ((size_t)krow * p.Nk + R) * p.ldk + p.k_off + head * DP + ch * 8;
+    vptr[i] = p.vt + (((size_t)vrow * p.heads + head) * DP + R) * (size_t)p.ldv + ch * 8;
+  }
+  auto issue_k = [&](int slot, int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kptr[i] + (size_t)kv0 * p.ldk), (lds_ptr_t)(smem + slot * 2 * KT + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+  auto issue_v = [&](int slot, int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vptr[i] + kv0), (lds_ptr_t)(smem + slot * 2 * KT + KT + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+  const int x7 = ql & 7;
+  const int lane_row_off = (ql >> 4) * 2048 + (ql & 7) * 256 + ((ql >> 3) & 1) * 128;
+  auto scores = [&](int slot, int st) {
+    const char* sK = smem + slot * 2 * KT + lane_row_off + st * 4096;
+    floatx16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) s = mfma32(*reinterpret_cast<const half8*>(sK + (((ks * 2 + h) ^ x7) * 16)), qf[ks], s);
+    return s;
+  };
+  auto rowmax = [&](const floatx16& s) {
+    float m = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, s[r]);
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+  };
+  auto move_reference = [&](floatx16& s, float mloc, bool first) {      // as in attn_flash_dma64_kernel's AUG branch, on a 32-key half
+    const bool grow = first || mloc > 8.0f;
+    if (__any(grow)) {
+      const float target = mrun + ((first || mloc > 0.f) ? mloc : 0.f);
+      const half_t mh = (half_t)target;
+      const float mnew = (float)mh;
+      const float delta = mnew - mrun;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ot][r] *= alpha;
+      mrun = mnew;
+      if (h == 1) qf[2][0] = (half_t)(-mnew);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] -= delta;
+    }
+  };
+  auto exp_pv = [&](const floatx16& s, int slot, int st) {
+    half8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(s[r]);
+    const char* sV = smem + slot * 2 * KT + KT + lane_row_off;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c0 = st * 4 + t * 2;
+        O[ot] = mfma32(*reinterpret_cast<const half8*>(sV + ot * 4096 + (((c0 + h) ^ x7) * 16)), pf[t], O[ot]);
+      }
+  };
+  const int nt = p.Nk / 64;
+  issue_k(0, 0);
+  issue_v(0, 0);
+  if (nt > 1) { issue_k(1, 64); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  floatx16 sa = scores(0, 0), sb;
+  float mloc = rowmax(sa);
+  for (int it = 0; it < nt; ++it) {
+    const int slot = it & 1;
+    const bool more = it + 1 < nt;
+    // ---- half 2 it: V^T(it) lands; V^T(it + 1) is requested into the other slot (V^T(it - 1) was last read in half 2 it - 1)
+    if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (more) issue_v(slot ^ 1, (it + 1) * 64);
+    move_reference(sa, mloc, it == 0);
+    sb = scores(slot, 1);
+    exp_pv(sa, slot, 0);
+    mloc = rowmax(sb);
+    if (PLACE == 1) PIPE_SCHED();
+    // ---- half 2 it + 1: K(it + 1) lands; K(it + 2) is requested into K(it)'s slot (last read just above)
+    if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < nt) issue_k(slot, (it + 2) * 64);
+    move_reference(sb, mloc, false);
+    if (more) sa = scores(slot ^ 1, 0);
+    exp_pv(sb, slot, 1);
+    if (more) mloc = rowmax(sa);
+    if (PLACE == 1) PIPE_SCHED();
+  }
+  const float lrow = O[1][4], lother = __shfl_xor(lrow, 32, 64);
+  const float ltot = h == 0 ? lrow : lother;
+  const float inv = 1.f / ltot;
+  if (p.lse && qok && h == 0) p.lse[((size_t)orow * p.heads + head) * p.Nq + qtok] = mrun + __log2f(ltot);
+  if (qok) {
+    half_t* op = p.o + ((size_t)orow * p.Nq + qtok) * p.ldo + head * p.dh;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = ot * 32 + 8 * g + 4 * h;
+        if (d + 3 < p.dh) {
+          half4 o4 = {(half_t)(O[ot][4 * g] * inv), (half_t)(O[ot][4 * g + 1] * inv), (half_t)(O[ot][4 * g + 2] * inv), (half_t)(O[ot][4 * g + 3] * inv)};
+          *reinterpret_cast<half4*>(op + d) = o4;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (d + j < p.dh) op[d + j] = (half_t)(O[ot][4 * g + j] * inv);
+        }
+      }
+  }
+}
+static int g_attn_pipe = 0;
+int attn_set_tuning_pipe(int v) { g_attn_pipe = v; return 0; }
+#else
+static const int g_attn_pipe = 0;
+int attn_set_tuning_pipe(int v) { return v == 0 ? 0 : -2; }      // the instance exists only in the ablation library
+#endif
+
 // which launches the 64-wide LDS-DMA kernel takes (the producer of V^T may then write the permuted key order)
 bool attn_flash_uses_dma64(int Dp, int Nk, int causal) {
   static const bool no_dma = getenv("PNPI_ATTN_NODMA") != nullptr;
@@ -438,6 +623,11 @@ int launch_attn_flash(const AttnP& p, hipStream_t st) {
     static const bool ksq3 = !(getenv("PNPI_ATTN_KSQ4") != nullptr);      // PNPI_ATTN_KSQ4: always four k-steps (A/B)
     static const bool no_aug = getenv("PNPI_ATTN_NOAUG") != nullptr;         // A/B: ignore AttnP::aug
     if (p.aug && p.dh == 40 && ksq3 && !no_aug) {
+#ifdef PNPI_ABLATIONS
+      if (p.vt_perm && g_attn_pipe == 1) attn_flash_pipe64_kernel<0><<<grid, 256, 0, st>>>(p);
+      else if (p.vt_perm && g_attn_pipe == 2) attn_flash_pipe64_kernel<1><<<grid, 256, 0, st>>>(p);
+      else
+#endif
       if (p.vt_perm) attn_flash_dma64_kernel<true, 3, true><<<grid, 256, 0, st>>>(p);
       else attn_flash_dma64_kernel<false, 3, true><<<grid, 256, 0, st>>>(p);
     } else if (p.dh <= 48 && ksq3) {

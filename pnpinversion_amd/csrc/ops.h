@@ -121,6 +121,7 @@ struct AttnP {
   float* lse = nullptr;           // optional [out_row][heads][Nq]: log2-domain log-sum-exp of every query (recording forward of the null-text path)
 };
 int launch_attn_flash(const AttnP& p, hipStream_t st);
+int attn_set_tuning_pipe(int v);        // tuning "attn_pipe" (ablation builds only): the half-tile software-pipelined forms of the 64-wide LDS-DMA kernel
 bool attn_flash_uses_dma64(int Dp, int Nk, int causal);
 
 // Flash-style attention backward (null-text path): dQ / dK / dV of softmax(scale Q K^T) V without the [N][N] matrices in memory.

@@ -63,8 +63,8 @@ def test_product_library_rejects_ablation_only_tuning_values():
     default kernel; pnpi_set_tuning answers them with an error in the product build (no GPU needed: process-global knobs)."""
     lib = _capi.load_library()
     for key, bad in ((b"igemm_vpp", 1), (b"igemm_vpp", 4), (b"igemm_sched", 1), (b"igemm_sched", 2), (b"igemm_v128", 11), (b"igemm_v128", 12),
-                     (b"igemm_v128", 15), (b"igemm_v320", 11), (b"igemm_v320", 12)):
+                     (b"igemm_v128", 15), (b"igemm_v320", 11), (b"igemm_v320", 12), (b"attn_pipe", 1), (b"attn_pipe", 2)):
         assert lib.pnpi_set_tuning(key, bad) != 0, (key, bad)
-    for key, ok in ((b"igemm_vpp", 0), (b"igemm_sched", 0), (b"igemm_v128", 2), (b"igemm_v320", 1), (b"gn_slab", 0)):     # the defaults are accepted
+    for key, ok in ((b"igemm_vpp", 0), (b"igemm_sched", 0), (b"igemm_v128", 2), (b"igemm_v320", 1), (b"gn_slab", 0), (b"attn_pipe", 0)):     # the defaults are accepted
         assert lib.pnpi_set_tuning(key, ok) == 0, (key, ok)
     assert lib.pnpi_set_tuning(b"no_such_knob", 1) != 0
